@@ -1,0 +1,1362 @@
+// oracle.cpp -- CPU restatement of the L3STER element-local hot path.  TEST INFRASTRUCTURE, NOT PRODUCT (see oracle.h).
+//
+// Every function cites the reference file:line (relative to /root/reference) whose algorithm it restates.  Where the
+// reference delegates to Eigen (dense products, 3x3 inverse, eigen-solvers for the tables) the published algorithm is
+// restated directly; table generators use better-conditioned formulas (Newton on Legendre polynomials, product-form
+// Lagrange basis) than the reference's companion-matrix / monomial route, which changes table
+// entries by <= 1e-14 at p <= 6.
+//
+// Build: g++ -O3 -march=native -std=c++20 -shared -fPIC oracle.cpp -o liboracle.so -lpthread   (oracle/Makefile)
+
+#include "oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace
+{
+thread_local std::string g_err;
+int                      fail(int code, const char* msg)
+{
+    g_err = msg;
+    return code;
+}
+
+using ld = long double;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Legendre polynomial P_n and derivative (three-term recurrence).  math/Legendre.hpp:9-49 builds the coefficients of the
+// same polynomials; evaluation by recurrence is the well-conditioned equivalent.
+void legendre(int n, ld x, ld& P, ld& dP)
+{
+    ld p0 = 1, p1 = x;
+    if (n == 0)
+    {
+        P  = 1;
+        dP = 0;
+        return;
+    }
+    for (int k = 2; k <= n; ++k)
+    {
+        const ld pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+        p0          = p1;
+        p1          = pk;
+    }
+    P  = p1;
+    dP = n * (x * p1 - p0) / (x * x - 1); // valid for |x| != 1
+}
+
+// GLL abscissae: {-1, roots of P'_{n-1}, +1}.  math/LobattoRuleAbsc.hpp:11-35 (roots via math/Polynomial.hpp:98-122).
+std::vector< double > gllNodes(int n)
+{
+    std::vector< double > x(n);
+    if (n == 2)
+        return {-1., 1.};
+    if (n == 3)
+        return {-1., 0., 1.};
+    const int N = n - 1;
+    x[0]        = -1.;
+    x[n - 1]    = 1.;
+    const ld pi = acosl(-1.0L);
+    for (int k = 1; k < n - 1; ++k)
+    {
+        ld xk = -cosl(pi * k / N);
+        for (int it = 0; it < 100; ++it)
+        {
+            ld P, dP;
+            legendre(N, xk, P, dP);
+            const ld d2P = (2 * xk * dP - N * (N + 1) * P) / (1 - xk * xk);
+            const ld dx  = dP / d2P;
+            xk -= dx;
+            if (fabsl(dx) < 1e-19L)
+                break;
+        }
+        x[k] = static_cast< double >(xk);
+    }
+    for (int k = 0; k < n / 2; ++k) // enforce exact symmetry (the closed forms are symmetric, tests/MathTests.cpp:168-214)
+    {
+        const double a = 0.5 * (x[n - 1 - k] - x[k]);
+        x[k]           = -a;
+        x[n - 1 - k]   = a;
+    }
+    if (n % 2)
+        x[n / 2] = 0.;
+    return x;
+}
+
+// Gauss-Legendre rule.  math/ComputeGaussRule.hpp:26-60 (Golub-Welsch in long double, ascending eigenvalues, weights
+// 2*v0^2) called from quad/ReferenceQuadrature.hpp:24-51; the same nodes/weights by Newton on P_n in long double.
+void glRule(int nq, std::vector< double >& x, std::vector< double >& w)
+{
+    x.assign(nq, 0.);
+    w.assign(nq, 0.);
+    const ld pi = acosl(-1.0L);
+    for (int i = 0; i < nq; ++i)
+    {
+        ld xi = -cosl(pi * (i + 0.75L) / (nq + 0.5L));
+        ld P, dP;
+        for (int it = 0; it < 100; ++it)
+        {
+            legendre(nq, xi, P, dP);
+            const ld dx = P / dP;
+            xi -= dx;
+            if (fabsl(dx) < 1e-19L)
+                break;
+        }
+        legendre(nq, xi, P, dP);
+        x[i] = static_cast< double >(xi);
+        w[i] = static_cast< double >(2 / ((1 - xi * xi) * dP * dP));
+    }
+    if (nq % 2)
+        x[nq / 2] = 0.;
+}
+
+// 1-D Lagrange basis on `nodes` at x: values and derivatives (product form).  basisfun/ReferenceBasisFunction.hpp:28-72
+// evaluates the same polynomials from monomial coefficients (math/LagrangeInterpolation.hpp:13-41).
+void lagrange1d(const std::vector< double >& nodes, double x, double* vals, double* ders)
+{
+    const int n = static_cast< int >(nodes.size());
+    for (int b = 0; b < n; ++b)
+    {
+        ld denom = 1;
+        for (int j = 0; j < n; ++j)
+            if (j != b)
+                denom *= (ld{nodes[b]} - nodes[j]);
+        ld val = 1;
+        for (int j = 0; j < n; ++j)
+            if (j != b)
+                val *= (ld{x} - nodes[j]);
+        ld der = 0;
+        for (int k = 0; k < n; ++k)
+        {
+            if (k == b)
+                continue;
+            ld prod = 1;
+            for (int j = 0; j < n; ++j)
+                if (j != b && j != k)
+                    prod *= (ld{x} - nodes[j]);
+            der += prod;
+        }
+        vals[b] = static_cast< double >(val / denom);
+        if (ders)
+            ders[b] = static_cast< double >(der / denom);
+    }
+}
+
+struct Tables1D
+{
+    int                   n, nq;
+    std::vector< double > gll, qx, qw;
+    std::vector< double > I, D; // row-major [n][nq]   algsys/SumFactorization.hpp:25-49
+};
+
+Tables1D makeTables(int p, int nq)
+{
+    Tables1D t;
+    t.n   = p + 1;
+    t.nq  = nq;
+    t.gll = gllNodes(p + 1);
+    glRule(nq, t.qx, t.qw);
+    t.I.assign(static_cast< size_t >(t.n) * nq, 0.);
+    t.D.assign(static_cast< size_t >(t.n) * nq, 0.);
+    std::vector< double > v(t.n), d(t.n);
+    for (int q = 0; q < nq; ++q)
+    {
+        lagrange1d(t.gll, t.qx[q], v.data(), d.data());
+        for (int b = 0; b < t.n; ++b)
+        {
+            t.I[b * nq + q] = v[b];
+            t.D[b * nq + q] = d[b];
+        }
+    }
+    return t;
+}
+
+int ipow(int b, int e)
+{
+    int r = 1;
+    while (e--)
+        r *= b;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel interface.  common/KernelInterface.hpp:13-57: Result{operators[D+1] (E x U), rhs (E x R)} zero-initialised
+// (:61-68) before the user callable fills it; DomainInput{field_vals[F], field_ders[D][F], point{space,time}}.
+struct KParams
+{
+    int dim, E, U, F;
+};
+struct KIn
+{
+    const double* fv;    // [F]
+    const double* fd[3]; // [D][F]
+    double        x, y, z, t;
+    const double* kp;    // kernel parameter block or nullptr
+};
+struct KOut
+{
+    double* A[4]; // each row-major E x U
+    double* rhs;  // row-major E x R
+    int     U, R;
+    double& op(int d, int i, int j) { return A[d][i * U + j]; }
+    double& f(int i, int j = 0) { return rhs[i * R + j]; }
+};
+using KFun = void (*)(const KIn&, KOut&);
+
+// tests/Kernels.hpp:55-81 and benchmarks/Diffusion3D.hpp:51-79 (k = s = 1; the test kernel leaves rhs = 0: kp[1] = 0)
+void kDiffusion3D(const KIn& in, KOut& o)
+{
+    const double k = in.kp ? in.kp[0] : 1., s = in.kp ? in.kp[1] : 1.;
+    o.op(1, 0, 1) = -k;
+    o.op(2, 0, 2) = -k;
+    o.op(3, 0, 3) = -k;
+    o.f(0)        = s;
+    o.op(0, 1, 1) = -1.;
+    o.op(1, 1, 0) = 1.;
+    o.op(0, 2, 2) = -1.;
+    o.op(2, 2, 0) = 1.;
+    o.op(0, 3, 3) = -1.;
+    o.op(3, 3, 0) = 1.;
+    o.op(2, 4, 3) = 1.;
+    o.op(3, 4, 2) = -1.;
+    o.op(1, 5, 3) = -1.;
+    o.op(3, 5, 1) = 1.;
+    o.op(1, 6, 2) = 1.;
+    o.op(2, 6, 1) = -1.;
+}
+// tests/Kernels.hpp:84-118
+void kDiffusion3DVar(const KIn& in, KOut& o)
+{
+    const double lambda = in.fv[0];
+    o.op(0, 0, 1)       = -in.fd[0][0];
+    o.op(0, 0, 2)       = -in.fd[1][0];
+    o.op(0, 0, 3)       = -in.fd[2][0];
+    o.op(1, 0, 1)       = -lambda;
+    o.op(2, 0, 2)       = -lambda;
+    o.op(3, 0, 3)       = -lambda;
+    o.op(0, 1, 1)       = -1.;
+    o.op(1, 1, 0)       = 1.;
+    o.op(0, 2, 2)       = -1.;
+    o.op(2, 2, 0)       = 1.;
+    o.op(0, 3, 3)       = -1.;
+    o.op(3, 3, 0)       = 1.;
+    o.op(2, 4, 3)       = 1.;
+    o.op(3, 4, 2)       = -1.;
+    o.op(1, 5, 3)       = -1.;
+    o.op(3, 5, 1)       = 1.;
+    o.op(1, 6, 2)       = 1.;
+    o.op(2, 6, 1)       = -1.;
+}
+// tests/Kernels.hpp:5-24
+void kDiffusion2D(const KIn&, KOut& o)
+{
+    o.op(1, 0, 1) = -1.;
+    o.op(2, 0, 2) = -1.;
+    o.op(0, 1, 1) = -1.;
+    o.op(1, 1, 0) = 1.;
+    o.op(0, 2, 2) = -1.;
+    o.op(2, 2, 0) = 1.;
+    o.op(1, 3, 2) = 1.;
+    o.op(2, 3, 1) = -1.;
+}
+// tests/Kernels.hpp:27-52
+void kDiffusion2DVar(const KIn& in, KOut& o)
+{
+    const double lambda = in.fv[0];
+    o.op(0, 0, 1)       = -in.fd[0][0];
+    o.op(0, 0, 2)       = -in.fd[1][0];
+    o.op(1, 0, 1)       = -lambda;
+    o.op(2, 0, 2)       = -lambda;
+    o.op(0, 1, 1)       = -1.;
+    o.op(1, 1, 0)       = 1.;
+    o.op(0, 2, 2)       = -1.;
+    o.op(2, 2, 0)       = 1.;
+    o.op(1, 3, 2)       = 1.;
+    o.op(2, 3, 1)       = -1.;
+}
+// Synthetic config-5 kernel: unknowns (c, qx, qy, qz); Diffusion3D rows with the transport
+// equation sigma*c + u.grad c - k div q = s, u = 3 interpolated fields.  kp = {k, sigma, s}.
+void kAdvDiff3D(const KIn& in, KOut& o)
+{
+    const double k = in.kp ? in.kp[0] : 1., sigma = in.kp ? in.kp[1] : 1., s = in.kp ? in.kp[2] : 1.;
+    o.op(0, 0, 0) = sigma;
+    o.op(1, 0, 0) = in.fv[0];
+    o.op(2, 0, 0) = in.fv[1];
+    o.op(3, 0, 0) = in.fv[2];
+    o.op(1, 0, 1) = -k;
+    o.op(2, 0, 2) = -k;
+    o.op(3, 0, 3) = -k;
+    o.f(0)        = s;
+    o.op(0, 1, 1) = -1.;
+    o.op(1, 1, 0) = 1.;
+    o.op(0, 2, 2) = -1.;
+    o.op(2, 2, 0) = 1.;
+    o.op(0, 3, 3) = -1.;
+    o.op(3, 3, 0) = 1.;
+    o.op(2, 4, 3) = 1.;
+    o.op(3, 4, 2) = -1.;
+    o.op(1, 5, 3) = -1.;
+    o.op(3, 5, 1) = 1.;
+    o.op(1, 6, 2) = 1.;
+    o.op(2, 6, 1) = -1.;
+}
+
+struct KernelEntry
+{
+    KParams kp;
+    KFun    fun;
+};
+const KernelEntry* getKernel(int id)
+{
+    static const KernelEntry table[] = {{{3, 7, 4, 0}, kDiffusion3D},
+                                        {{3, 7, 4, 1}, kDiffusion3DVar},
+                                        {{2, 4, 3, 0}, kDiffusion2D},
+                                        {{2, 4, 3, 1}, kDiffusion2DVar},
+                                        {{3, 7, 4, 3}, kAdvDiff3D}};
+    if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
+        return nullptr;
+    return &table[id];
+}
+
+// common/KernelInterface.hpp:102-119 (DomainEquationKernel::operator(): zero-init + invoke)
+struct KernelEval
+{
+    const KernelEntry*    k;
+    int                   R;
+    std::vector< double > store;
+    KOut                  out;
+    KernelEval(const KernelEntry* k_, int R_) : k{k_}, R{R_}
+    {
+        const auto& [dim, E, U, F] = k->kp;
+        store.assign(static_cast< size_t >((dim + 1) * E * U + E * R), 0.);
+        for (int d = 0; d <= dim; ++d)
+            out.A[d] = store.data() + d * E * U;
+        out.rhs = store.data() + (dim + 1) * E * U;
+        out.U   = U;
+        out.R   = R;
+    }
+    void operator()(const KIn& in)
+    {
+        std::fill(store.begin(), store.end(), 0.);
+        k->fun(in, out);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Geometry.  mapping/JacobiMat.hpp:15-45: J[d][s] = sum_v x_v[s] dN_v/dxi_d with N_v the order-1 Lagrange basis,
+// vertex v = i + 2j (+ 4k).
+void linBasis(double x, double* v, double* d)
+{
+    v[0] = 0.5 * (1. - x);
+    v[1] = 0.5 * (1. + x);
+    d[0] = -0.5;
+    d[1] = 0.5;
+}
+void jacobiMat(int dim, const double* verts, const double* pt, double* J)
+{
+    double v[3][2], d[3][2];
+    for (int a = 0; a < dim; ++a)
+        linBasis(pt[a], v[a], d[a]);
+    for (int i = 0; i < dim * dim; ++i)
+        J[i] = 0.;
+    const int nv = 1 << dim;
+    for (int vi = 0; vi < nv; ++vi)
+    {
+        const int idx[3] = {vi & 1, (vi >> 1) & 1, (vi >> 2) & 1};
+        for (int dd = 0; dd < dim; ++dd)
+        {
+            double sf = 1.;
+            for (int a = 0; a < dim; ++a)
+                sf *= (a == dd) ? d[a][idx[a]] : v[a][idx[a]];
+            for (int s = 0; s < dim; ++s)
+                J[dd * dim + s] += verts[vi * 3 + s] * sf;
+        }
+    }
+}
+// mapping/MapReferenceToPhysical.hpp:14-25
+void mapToPhysical(int dim, const double* verts, const double* pt, double* xyz)
+{
+    double v[3][2], d[3][2];
+    for (int a = 0; a < dim; ++a)
+        linBasis(pt[a], v[a], d[a]);
+    xyz[0] = xyz[1] = xyz[2] = 0.;
+    const int nv             = 1 << dim;
+    for (int vi = 0; vi < nv; ++vi)
+    {
+        const int idx[3] = {vi & 1, (vi >> 1) & 1, (vi >> 2) & 1};
+        double    sf     = 1.;
+        for (int a = 0; a < dim; ++a)
+            sf *= v[a][idx[a]];
+        for (int s = 0; s < 3; ++s)
+            xyz[s] += verts[vi * 3 + s] * sf;
+    }
+}
+// determinant and inverse of a dim x dim matrix (Eigen fixed-size inverse() = cofactor formula)
+double det(int dim, const double* M)
+{
+    if (dim == 2)
+        return M[0] * M[3] - M[1] * M[2];
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+void inverse(int dim, const double* M, double* Mi)
+{
+    const double dt = det(dim, M), id = 1. / dt;
+    if (dim == 2)
+    {
+        Mi[0] = M[3] * id;
+        Mi[1] = -M[1] * id;
+        Mi[2] = -M[2] * id;
+        Mi[3] = M[0] * id;
+        return;
+    }
+    Mi[0] = (M[4] * M[8] - M[5] * M[7]) * id;
+    Mi[1] = (M[2] * M[7] - M[1] * M[8]) * id;
+    Mi[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    Mi[3] = (M[5] * M[6] - M[3] * M[8]) * id;
+    Mi[4] = (M[0] * M[8] - M[2] * M[6]) * id;
+    Mi[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    Mi[6] = (M[3] * M[7] - M[4] * M[6]) * id;
+    Mi[7] = (M[1] * M[6] - M[0] * M[7]) * id;
+    Mi[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reference basis at the tensor quadrature for the local-element path.
+// quad/GenerateQuadrature.hpp:18-77: QP index with xi slowest;  basisfun/ReferenceBasisFunction.hpp:74-153: tensor
+// basis, I = ix + n*(iy + n*iz);  basisfun/ReferenceElementBasisAtQuadrature.hpp:10-19.
+struct RefBasis
+{
+    int                   dim, N, nqp;
+    std::vector< double > vals;    // [nqp][N]
+    std::vector< double > ders;    // [nqp][dim][N]
+    std::vector< double > weights; // [nqp]
+    std::vector< double > points;  // [nqp][dim]
+};
+RefBasis makeRefBasis(int dim, int p, int nq)
+{
+    const Tables1D t = makeTables(p, nq);
+    RefBasis       rb;
+    rb.dim = dim;
+    rb.N   = ipow(p + 1, dim);
+    rb.nqp = ipow(nq, dim);
+    rb.vals.assign(static_cast< size_t >(rb.nqp) * rb.N, 0.);
+    rb.ders.assign(static_cast< size_t >(rb.nqp) * dim * rb.N, 0.);
+    rb.weights.assign(rb.nqp, 0.);
+    rb.points.assign(static_cast< size_t >(rb.nqp) * dim, 0.);
+    const int n = p + 1;
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        int q[3] = {0, 0, 0};
+        if (dim == 2)
+        {
+            q[0] = qi / nq;
+            q[1] = qi % nq;
+        }
+        else
+        {
+            q[0] = qi / (nq * nq);
+            q[1] = (qi / nq) % nq;
+            q[2] = qi % nq;
+        }
+        double w = 1.;
+        for (int a = 0; a < dim; ++a)
+        {
+            w *= t.qw[q[a]];
+            rb.points[qi * dim + a] = t.qx[q[a]];
+        }
+        rb.weights[qi] = w;
+        for (int b = 0; b < rb.N; ++b)
+        {
+            const int bi[3] = {b % n, (b / n) % n, b / (n * n)};
+            double    val   = 1.;
+            for (int a = 0; a < dim; ++a)
+                val *= t.I[bi[a] * nq + q[a]];
+            rb.vals[static_cast< size_t >(qi) * rb.N + b] = val;
+            for (int dd = 0; dd < dim; ++dd)
+            {
+                double dv = 1.;
+                for (int a = 0; a < dim; ++a)
+                    dv *= (a == dd) ? t.D[bi[a] * nq + q[a]] : t.I[bi[a] * nq + q[a]];
+                rb.ders[(static_cast< size_t >(qi) * dim + dd) * rb.N + b] = dv;
+            }
+        }
+    }
+    return rb;
+}
+
+// One quadrature point of the local-element path: mapDomain (mapping/MapReferenceToPhysical.hpp:27-42,69-78:
+// phys_ders = J^{-1} ref_ders, jacobian = det J) + evalKernel (algsys/AssembleLocalSystem.hpp:54-75,218-232).
+struct QpData
+{
+    std::vector< double > phys; // [dim][N]
+    double                jac;
+};
+void processQp(const RefBasis&  rb,
+               int              qi,
+               const double*    verts,
+               const double*    node_fields,
+               const double*    kparams,
+               double           time,
+               KernelEval&      ke,
+               QpData&          qd,
+               std::vector< double >& scratch)
+{
+    const int     dim = rb.dim, N = rb.N, F = ke.k->kp.F;
+    const double* pt = &rb.points[static_cast< size_t >(qi) * dim];
+    double        J[9], Ji[9];
+    jacobiMat(dim, verts, pt, J);
+    inverse(dim, J, Ji);
+    qd.jac = det(dim, J);
+    qd.phys.assign(static_cast< size_t >(dim) * N, 0.);
+    const double* rd = &rb.ders[static_cast< size_t >(qi) * dim * N];
+    for (int s = 0; s < dim; ++s)
+        for (int dd = 0; dd < dim; ++dd)
+        {
+            const double c = Ji[s * dim + dd];
+            for (int b = 0; b < N; ++b)
+                qd.phys[s * N + b] += c * rd[dd * N + b];
+        }
+    // field values / derivatives:  node_vals^T * basis_vals,  phys_ders * node_vals
+    scratch.assign(static_cast< size_t >((dim + 1) * std::max(F, 1)), 0.);
+    const double* bv = &rb.vals[static_cast< size_t >(qi) * N];
+    for (int f = 0; f < F; ++f)
+    {
+        double v = 0.;
+        for (int b = 0; b < N; ++b)
+            v += node_fields[b * F + f] * bv[b];
+        scratch[f] = v;
+        for (int s = 0; s < dim; ++s)
+        {
+            double dv = 0.;
+            for (int b = 0; b < N; ++b)
+                dv += qd.phys[s * N + b] * node_fields[b * F + f];
+            scratch[(s + 1) * F + f] = dv;
+        }
+    }
+    double xyz[3];
+    mapToPhysical(dim, verts, pt, xyz);
+    KIn in{};
+    in.fv = scratch.data();
+    for (int s = 0; s < dim; ++s)
+        in.fd[s] = scratch.data() + (s + 1) * F;
+    in.x  = xyz[0];
+    in.y  = xyz[1];
+    in.z  = xyz[2];
+    in.t  = time;
+    in.kp = kparams;
+    ke(in);
+}
+
+// B_q^T block of one basis function: block[u][e] = phi*A0[e][u] + sum_d dphi_d*A_d[e][u]
+// algsys/AssembleLocalSystem.hpp:131-142 (makeBasisBlock), algsys/EvaluateLocalOperator.hpp:26-34 (computeATrans)
+inline void basisBlock(const KernelEval& ke, int dim, int E, int U, double bv, const double* phys, int N, int b,
+                       double* block /*[U][E]*/)
+{
+    for (int u = 0; u < U; ++u)
+        for (int e = 0; e < E; ++e)
+        {
+            double v = bv * ke.out.A[0][e * U + u];
+            for (int dd = 0; dd < dim; ++dd)
+                v += phys[dd * N + b] * ke.out.A[dd + 1][e * U + u];
+            block[u * E + e] = v;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sum-factorisation sweeps.  algsys/SumFactorization.hpp:67-86: out = in^T * M on column-major maps:
+// in is n_in x C (col-major), M is n_in x n_out (row-major), out is C x n_out (col-major).
+void sweepStd(const double* in, int n_in, int C, const double* M, int n_out, double* out, bool accumulate)
+{
+    for (int q = 0; q < n_out; ++q)
+        for (int c = 0; c < C; ++c)
+        {
+            double acc = 0.;
+            for (int b = 0; b < n_in; ++b)
+                acc += in[b + static_cast< size_t >(n_in) * c] * M[b * n_out + q];
+            double& o = out[c + static_cast< size_t >(C) * q];
+            o         = accumulate ? o + acc : acc;
+        }
+}
+
+// Odd-even decomposition.  algsys/SumFactorization.hpp:88-157 (psi+-), :159-203 (makeEO / reconstructOddEven),
+// :205-258 (block kernels).  `is_der` selects the derivative variant (e' and o' swap roles, :233).
+struct PsiPM
+{
+    int                   rows, cols, pr, pc, mr, mc;
+    std::vector< double > plus, minus; // row-major pr x pc, mr x mc
+};
+PsiPM makePsi(const double* M, int rows, int cols, bool is_der)
+{
+    PsiPM s;
+    s.rows = rows;
+    s.cols = cols;
+    s.pr   = (rows + 1) / 2;
+    s.mr   = rows / 2;
+    s.pc   = is_der ? cols / 2 : (cols + 1) / 2;
+    s.mc   = is_der ? (cols + 1) / 2 : cols / 2;
+    s.plus.assign(static_cast< size_t >(s.pr) * s.pc, 0.);
+    s.minus.assign(static_cast< size_t >(s.mr) * s.mc, 0.);
+    for (int r = 0; r < rows / 2; ++r)
+        for (int c = 0; c < s.pc; ++c)
+            s.plus[r * s.pc + c] = M[r * cols + c] + M[(rows - r - 1) * cols + c];
+    if (rows % 2)
+        for (int c = 0; c < s.pc; ++c)
+            s.plus[(s.pr - 1) * s.pc + c] = M[(rows / 2) * cols + c];
+    for (int r = 0; r < s.mr; ++r)
+        for (int c = 0; c < s.mc; ++c)
+            s.minus[r * s.mc + c] = M[r * cols + c] - M[(rows - r - 1) * cols + c];
+    return s;
+}
+void sweepOddEven(const double* in, int C, const PsiPM& psi, bool is_der, double* out, bool accumulate)
+{
+    const int             rows = psi.rows, cols = psi.cols;
+    std::vector< double > e(psi.pr), o(psi.mr), ep(psi.pc), op(psi.mc);
+    for (int c = 0; c < C; ++c)
+    {
+        const double* col = in + static_cast< size_t >(rows) * c;
+        for (int r = 0; r < psi.mr; ++r)
+        {
+            const double v1 = col[r], v2 = col[rows - r - 1];
+            e[r] = .5 * (v1 + v2);
+            o[r] = .5 * (v1 - v2);
+        }
+        if (psi.mr < psi.pr)
+            e[psi.mr] = col[psi.mr];
+        for (int k = 0; k < psi.pc; ++k)
+        {
+            double acc = 0.;
+            for (int r = 0; r < psi.pr; ++r)
+                acc += e[r] * psi.plus[r * psi.pc + k];
+            ep[k] = acc;
+        }
+        for (int k = 0; k < psi.mc; ++k)
+        {
+            double acc = 0.;
+            for (int r = 0; r < psi.mr; ++r)
+                acc += o[r] * psi.minus[r * psi.mc + k];
+            op[k] = acc;
+        }
+        // reconstructOddEven(out, first, second): interp -> (e', o'); der -> (o', e')
+        const double* first   = is_der ? op.data() : ep.data();
+        const double* second  = is_der ? ep.data() : op.data();
+        const int     n_first = is_der ? psi.mc : psi.pc, n_second = is_der ? psi.pc : psi.mc;
+        auto          put = [&](int q, double v) {
+            double& dst = out[c + static_cast< size_t >(C) * q];
+            dst         = accumulate ? dst + v : v;
+        };
+        for (int k = 0; k < n_second; ++k)
+        {
+            put(k, first[k] + second[k]);
+            put(cols - k - 1, first[k] - second[k]);
+        }
+        if (n_first > n_second)
+            put(n_second, first[n_first - 1]);
+    }
+}
+
+struct SweepSet
+{
+    int                   n, nq;
+    bool                  odd_even;
+    std::vector< double > I, D, It, Dt; // I,D: n x nq; It,Dt: nq x n (row-major)   SumFactorization.hpp:51-65
+    PsiPM                 pIb, pDb, pIf, pDf;
+    SweepSet(const Tables1D& t, bool oe) : n{t.n}, nq{t.nq}, odd_even{oe}, I{t.I}, D{t.D}
+    {
+        It.assign(I.size(), 0.);
+        Dt.assign(D.size(), 0.);
+        for (int b = 0; b < n; ++b)
+            for (int q = 0; q < nq; ++q)
+            {
+                It[q * n + b] = I[b * nq + q];
+                Dt[q * n + b] = D[b * nq + q];
+            }
+        pIb = makePsi(I.data(), n, nq, false);
+        pDb = makePsi(D.data(), n, nq, true);
+        pIf = makePsi(It.data(), nq, n, false);
+        pDf = makePsi(Dt.data(), nq, n, true);
+    }
+    // the four primitives, SumFactorization.hpp:344-383
+    void backInterp(const double* in, int C, double* out) const
+    {
+        odd_even ? sweepOddEven(in, C, pIb, false, out, false) : sweepStd(in, n, C, I.data(), nq, out, false);
+    }
+    void backDer(const double* in, int C, double* out) const
+    {
+        odd_even ? sweepOddEven(in, C, pDb, true, out, false) : sweepStd(in, n, C, D.data(), nq, out, false);
+    }
+    void fwdInterpAssign(const double* in, int C, double* out) const
+    {
+        odd_even ? sweepOddEven(in, C, pIf, false, out, false) : sweepStd(in, nq, C, It.data(), n, out, false);
+    }
+    void fwdDerAccumulate(const double* in, int C, double* out) const
+    {
+        odd_even ? sweepOddEven(in, C, pDf, true, out, true) : sweepStd(in, nq, C, Dt.data(), n, out, true);
+    }
+};
+
+// sumFactBackHex / sumFactBackQuad: algsys/SumFactorization.hpp:438-504.  `fill` holds the col-major [node][field]
+// input; r[] are the dim+1 result buffers (row-major [qi][field]); same buffer-reuse order as the reference.
+void sumFactBack(const SweepSet& s, int dim, int nf, const double* fill, std::vector< double > r[4])
+{
+    const int    n = s.n, nq = s.nq;
+    const size_t sz = static_cast< size_t >(ipow(std::max(n, nq), dim)) * nf;
+    for (int i = 0; i <= dim; ++i)
+        r[i].assign(sz, 0.);
+    std::vector< double > temp(sz, 0.);
+    if (dim == 2)
+    {
+        std::copy(fill, fill + static_cast< size_t >(n) * n * nf, r[1].begin());
+        const int C0 = nf * n, C1 = nf * nq;
+        s.backInterp(r[1].data(), C0, temp.data()); // :460
+        s.backDer(temp.data(), C1, r[2].data());    // :461
+        s.backInterp(temp.data(), C1, r[0].data()); // :462
+        s.backDer(r[1].data(), C0, temp.data());    // :463
+        s.backInterp(temp.data(), C1, r[1].data()); // :464
+    }
+    else
+    {
+        std::copy(fill, fill + static_cast< size_t >(n) * n * n * nf, r[3].begin());
+        const int C0 = nf * n * n, C1 = nf * nq * n, C2 = nf * nq * nq;
+        s.backInterp(r[3].data(), C0, r[0].data());   // :493
+        s.backDer(r[3].data(), C0, r[1].data());      // :494
+        s.backInterp(r[1].data(), C1, r[3].data());   // :495
+        s.backInterp(r[3].data(), C2, r[1].data());   // :496  -> d/dxi
+        s.backDer(r[0].data(), C1, r[3].data());      // :497
+        s.backInterp(r[3].data(), C2, r[2].data());   // :498  -> d/deta
+        s.backInterp(r[0].data(), C1, temp.data());   // :499
+        s.backInterp(temp.data(), C2, r[0].data());   // :500  -> values
+        s.backDer(temp.data(), C2, r[3].data());      // :501  -> d/dzeta
+    }
+}
+// sumFactForwardHex / Quad: algsys/SumFactorization.hpp:758-814; result in t[0] (row-major [node][field])
+void sumFactForward(const SweepSet& s, int dim, int nf, std::vector< double > t[4], std::vector< double >& temp)
+{
+    const int n = s.n, nq = s.nq;
+    if (dim == 2)
+    {
+        const int C0 = nf * nq, C1 = nf * n;
+        s.fwdInterpAssign(t[0].data(), C0, temp.data());  // :777
+        s.fwdDerAccumulate(t[1].data(), C0, temp.data()); // :778
+        s.fwdInterpAssign(temp.data(), C1, t[0].data());  // :779
+        s.fwdInterpAssign(t[2].data(), C0, temp.data());  // :780
+        s.fwdDerAccumulate(temp.data(), C1, t[0].data()); // :781
+    }
+    else
+    {
+        const int C0 = nf * nq * nq, C1 = nf * n * nq, C2 = nf * n * n;
+        s.fwdInterpAssign(t[0].data(), C0, temp.data());  // :805
+        s.fwdDerAccumulate(t[1].data(), C0, temp.data()); // :806
+        s.fwdInterpAssign(temp.data(), C1, t[1].data());  // :807
+        s.fwdInterpAssign(t[2].data(), C0, temp.data());  // :808
+        s.fwdDerAccumulate(temp.data(), C1, t[1].data()); // :809
+        s.fwdInterpAssign(t[1].data(), C2, t[0].data());  // :810
+        s.fwdInterpAssign(t[3].data(), C0, t[1].data());  // :811
+        s.fwdInterpAssign(t[1].data(), C1, t[3].data());  // :812
+        s.fwdDerAccumulate(t[3].data(), C2, t[0].data()); // :813
+    }
+}
+
+// Context for the sum-factorised element apply
+struct SumFactCtx
+{
+    int                dim, p, nq, R;
+    const KernelEntry* k;
+    Tables1D           tab, gtab;
+    SweepSet           sw, gsw;
+    bool               pass_true_z;
+    SumFactCtx(const KernelEntry* k_, int p_, int nq_, int R_, bool oe, bool true_z)
+        : dim{k_->kp.dim}, p{p_}, nq{nq_}, R{R_}, k{k_}, tab{makeTables(p_, nq_)}, gtab{makeTables(1, nq_)},
+          sw{tab, oe}, gsw{gtab, oe}, pass_true_z{true_z}
+    {}
+};
+
+// sumFactImpl: algsys/SumFactorization.hpp:816-868 with evalAtQuadQPs / evalAtHexQPs (:614-756) and
+// computeGeomDataLin (:506-537).  fill: col-major [node][op] (ops = U*R + F); result: row-major [node][U*R].
+void sumFactElement(const SumFactCtx& c, const double* verts, const double* fill, const double* kparams, double time,
+                    double* result)
+{
+    const int dim = c.dim, nq = c.nq, E = c.k->kp.E, U = c.k->kp.U, F = c.k->kp.F, R = c.R;
+    const int nops = U * R, nf = nops + F, nqp = ipow(nq, dim), nv = 1 << dim;
+
+    std::vector< double > back[4], geom[4], fwd[4];
+    sumFactBack(c.sw, dim, nf, fill, back);
+    // geometry: fill[i + nv*s] = vertex[i][s]  (:510-518, :526-535), num_fields = dim
+    std::vector< double > gfill(static_cast< size_t >(nv) * dim);
+    for (int i = 0; i < nv; ++i)
+        for (int s = 0; s < dim; ++s)
+            gfill[i + nv * s] = verts[i * 3 + s];
+    sumFactBack(c.gsw, dim, dim, gfill.data(), geom);
+
+    for (int i = 0; i <= dim; ++i)
+        fwd[i].assign(static_cast< size_t >(ipow(std::max(c.sw.n, nq), dim)) * nops, 0.);
+
+    KernelEval            ke{c.k, R};
+    std::vector< double > fdat(static_cast< size_t >((dim + 1) * std::max(F, 1)));
+    std::vector< double > Dm(static_cast< size_t >(dim) * E * U), t(static_cast< size_t >(E) * R);
+    for (int qi = 0; qi < nqp; ++qi)
+    {
+        // Jm[s][d] = d x_s / d xi_d (:539-570, :649, :716-724)
+        double Jm[9], Ji[9];
+        for (int s = 0; s < dim; ++s)
+            for (int d = 0; d < dim; ++d)
+                Jm[s * dim + d] = geom[d + 1][static_cast< size_t >(qi) * dim + s];
+        inverse(dim, Jm, Ji);
+        // fields (:572-612): values = rightCols<F> of the value buffer; dx_s[i] = sum_d Ji(d,s) * der_d[i]
+        for (int f = 0; f < F; ++f)
+        {
+            fdat[f] = back[0][static_cast< size_t >(qi) * nf + nops + f];
+            for (int s = 0; s < dim; ++s)
+            {
+                double v = 0.;
+                for (int d = 0; d < dim; ++d)
+                    v += Ji[d * dim + s] * back[d + 1][static_cast< size_t >(qi) * nf + nops + f];
+                fdat[(s + 1) * F + f] = v;
+            }
+        }
+        KIn in{};
+        in.fv = fdat.data();
+        for (int s = 0; s < dim; ++s)
+            in.fd[s] = fdat.data() + (s + 1) * F;
+        in.x = geom[0][static_cast< size_t >(qi) * dim + 0];
+        in.y = geom[0][static_cast< size_t >(qi) * dim + 1];
+        in.z = (dim == 3 && c.pass_true_z) ? geom[0][static_cast< size_t >(qi) * dim + 2] : 0.; // :656, :732 (D8)
+        in.t = time;
+        in.kp = kparams;
+        ke(in);
+        // D_d = sum_s A_s * Ji(d, s)   (:660-661, :736-738)
+        for (int d = 0; d < dim; ++d)
+            for (int i = 0; i < E * U; ++i)
+            {
+                double v = 0.;
+                for (int s = 0; s < dim; ++s)
+                    v += ke.out.A[s + 1][i] * Ji[d * dim + s];
+                Dm[d * E * U + i] = v;
+            }
+        // weight (:665-667, :743-745): qi = qx + nq*(qy + nq*qz)
+        double wgt = det(dim, Jm);
+        {
+            int rem = qi;
+            for (int a = 0; a < dim; ++a)
+            {
+                wgt *= c.tab.qw[rem % nq];
+                rem /= nq;
+            }
+        }
+        // t = wgt * (A0 t0 + sum_d D_d t_d), operands are U x R maps of the rows (:662-668, :739-746)
+        for (int e = 0; e < E; ++e)
+            for (int r = 0; r < R; ++r)
+            {
+                double acc = 0.;
+                for (int u = 0; u < U; ++u)
+                {
+                    acc += ke.out.A[0][e * U + u] * back[0][static_cast< size_t >(qi) * nf + r * U + u];
+                    for (int d = 0; d < dim; ++d)
+                        acc += Dm[d * E * U + e * U + u] * back[d + 1][static_cast< size_t >(qi) * nf + r * U + u];
+                }
+                t[e * R + r] = wgt * acc;
+            }
+        // r0 = A0^T t, r_d = D_d^T t into col-major [qi][op] buffers (:669-671, :747-750)
+        for (int r = 0; r < R; ++r)
+            for (int u = 0; u < U; ++u)
+            {
+                double a0 = 0.;
+                for (int e = 0; e < E; ++e)
+                    a0 += ke.out.A[0][e * U + u] * t[e * R + r];
+                fwd[0][qi + static_cast< size_t >(nqp) * (r * U + u)] = a0;
+                for (int d = 0; d < dim; ++d)
+                {
+                    double ad = 0.;
+                    for (int e = 0; e < E; ++e)
+                        ad += Dm[d * E * U + e * U + u] * t[e * R + r];
+                    fwd[d + 1][qi + static_cast< size_t >(nqp) * (r * U + u)] = ad;
+                }
+            }
+    }
+    sumFactForward(c.sw, dim, nops, fwd, back[0]); // second argument used as temp (:837, :864)
+    std::copy(fwd[0].begin(), fwd[0].begin() + static_cast< size_t >(ipow(c.sw.n, dim)) * nops, result);
+}
+
+template < typename F >
+void parallelFor(int64_t begin, int64_t end, int nthreads, F&& body)
+{
+    if (nthreads <= 1 || end - begin < 2)
+    {
+        body(begin, end, 0);
+        return;
+    }
+    std::vector< std::thread > pool;
+    const int64_t              chunk = (end - begin + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t)
+    {
+        const int64_t b = begin + t * chunk, e = std::min(end, b + chunk);
+        if (b >= e)
+            break;
+        pool.emplace_back([=, &body] { body(b, e, t); });
+    }
+    for (auto& th : pool)
+        th.join();
+}
+inline void atomicAdd(double& dst, double v, bool use_atomic)
+{
+    if (use_atomic)
+        std::atomic_ref< double >{dst}.fetch_add(v, std::memory_order_relaxed); // MatrixFreeSystem.hpp:481,513
+    else
+        dst += v;
+}
+} // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char* orc_last_error(void)
+{
+    return g_err.c_str();
+}
+
+int orc_kernel_params(int kernel_id, int* dim, int* n_eq, int* n_unk, int* n_fields)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    *dim      = k->kp.dim;
+    *n_eq     = k->kp.E;
+    *n_unk    = k->kp.U;
+    *n_fields = k->kp.F;
+    return 0;
+}
+
+int orc_gll_nodes(int n, double* x)
+{
+    if (n < 2)
+        return fail(-1, "n < 2");
+    const auto v = gllNodes(n);
+    std::copy(v.begin(), v.end(), x);
+    return 0;
+}
+int orc_gl_rule(int nq, double* x, double* w)
+{
+    if (nq < 1)
+        return fail(-1, "nq < 1");
+    std::vector< double > xv, wv;
+    glRule(nq, xv, wv);
+    std::copy(xv.begin(), xv.end(), x);
+    std::copy(wv.begin(), wv.end(), w);
+    return 0;
+}
+int orc_n_qps1d(int p, int value_order, int derivative_order)
+{
+    const int order = value_order * p + derivative_order * (p - 1); // AssemblyOptions::order, QO = 2*order
+    return (2 * order) / 2 + 1;                                     // getRefQuadSize
+}
+int orc_basis_1d(int p, int nq, double* I, double* D)
+{
+    const auto t = makeTables(p, nq);
+    std::copy(t.I.begin(), t.I.end(), I);
+    std::copy(t.D.begin(), t.D.end(), D);
+    return 0;
+}
+int orc_lagrange_1d(int p, double x, double* vals, double* ders)
+{
+    lagrange1d(gllNodes(p + 1), x, vals, ders);
+    return 0;
+}
+int orc_ref_basis_at_qps(int dim, int p, int nq, double* vals, double* ders, double* weights, double* points)
+{
+    const auto rb = makeRefBasis(dim, p, nq);
+    std::copy(rb.vals.begin(), rb.vals.end(), vals);
+    std::copy(rb.ders.begin(), rb.ders.end(), ders);
+    std::copy(rb.weights.begin(), rb.weights.end(), weights);
+    std::copy(rb.points.begin(), rb.points.end(), points);
+    return 0;
+}
+int orc_oddeven_check(int p, int nq, int cols, const double* in_back, const double* in_fwd, double* err)
+{
+    const auto t = makeTables(p, nq);
+    SweepSet   std_s{t, false}, oe_s{t, true};
+    const int  n = p + 1;
+    auto       cmp = [&](auto&& fa, auto&& fb, size_t out_size, const double* in, bool acc) {
+        std::vector< double > a(out_size, acc ? 0.25 : 0.), b(out_size, acc ? 0.25 : 0.);
+        fa(in, a.data());
+        fb(in, b.data());
+        double m = 0.;
+        for (size_t i = 0; i < out_size; ++i)
+            m = std::max(m, std::fabs(a[i] - b[i]));
+        return m;
+    };
+    err[0] = cmp([&](const double* i, double* o) { std_s.backInterp(i, cols, o); },
+                 [&](const double* i, double* o) { oe_s.backInterp(i, cols, o); },
+                 static_cast< size_t >(cols) * nq,
+                 in_back,
+                 false);
+    err[1] = cmp([&](const double* i, double* o) { std_s.backDer(i, cols, o); },
+                 [&](const double* i, double* o) { oe_s.backDer(i, cols, o); },
+                 static_cast< size_t >(cols) * nq,
+                 in_back,
+                 false);
+    err[2] = cmp([&](const double* i, double* o) { std_s.fwdInterpAssign(i, cols, o); },
+                 [&](const double* i, double* o) { oe_s.fwdInterpAssign(i, cols, o); },
+                 static_cast< size_t >(cols) * n,
+                 in_fwd,
+                 false);
+    err[3] = cmp([&](const double* i, double* o) { std_s.fwdDerAccumulate(i, cols, o); },
+                 [&](const double* i, double* o) { oe_s.fwdDerAccumulate(i, cols, o); },
+                 static_cast< size_t >(cols) * n,
+                 in_fwd,
+                 true);
+    return 0;
+}
+
+int orc_jacobi_mat(int dim, const double* verts, const double* point, double* J)
+{
+    jacobiMat(dim, verts, point, J);
+    return 0;
+}
+int orc_map_to_physical(int dim, const double* verts, const double* point, double* xyz)
+{
+    mapToPhysical(dim, verts, point, xyz);
+    return 0;
+}
+int orc_node_location(int dim, int p, const double* verts, int node, double* xyz)
+{
+    const auto   gll = gllNodes(p + 1);
+    const int    n   = p + 1;
+    const double pt[3] = {gll[node % n], gll[(node / n) % n], dim == 3 ? gll[node / (n * n)] : 0.};
+    mapToPhysical(dim, verts, pt, xyz);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int orc_assemble_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                       const double* kparams, double time, double* K, double* F_e)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const int      N = rb.N, Nd = N * U;
+    KernelEval     ke{k, R};
+    QpData         qd;
+    std::vector< double > scratch, block(static_cast< size_t >(U) * E), cols(static_cast< size_t >(Nd) * E);
+    std::fill(K, K + static_cast< size_t >(Nd) * Nd, 0.);
+    std::fill(F_e, F_e + static_cast< size_t >(Nd) * R, 0.);
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
+        if (!(qd.jac > 0.))
+            return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // AssembleLocalSystem.hpp:249
+        const double w = qd.jac * rb.weights[qi], sw = std::sqrt(std::fabs(w)), sgn = w >= 0. ? 1. : -1.;
+        // LocalSystemManager::update, AssembleLocalSystem.hpp:146-166
+        for (int b = 0; b < N; ++b)
+        {
+            basisBlock(ke, dim, E, U, rb.vals[static_cast< size_t >(qi) * N + b], qd.phys.data(), N, b, block.data());
+            for (int u = 0; u < U; ++u)
+            {
+                for (int r = 0; r < R; ++r)
+                {
+                    double acc = 0.;
+                    for (int e = 0; e < E; ++e)
+                        acc += block[u * E + e] * ke.out.rhs[e * R + r];
+                    F_e[(b * U + u) + static_cast< size_t >(Nd) * r] += acc * w;
+                }
+                for (int e = 0; e < E; ++e)
+                    cols[static_cast< size_t >(b * U + u) * E + e] = block[u * E + e] * sw;
+            }
+        }
+        // selfadjointView<Lower>.rankUpdate(batch, +-1), :192-208 (lower triangle only)
+        for (int i = 0; i < Nd; ++i)
+            for (int j = 0; j <= i; ++j)
+            {
+                double acc = 0.;
+                for (int e = 0; e < E; ++e)
+                    acc += cols[static_cast< size_t >(i) * E + e] * cols[static_cast< size_t >(j) * E + e];
+                K[static_cast< size_t >(i) * Nd + j] += sgn * acc;
+            }
+    }
+    // getSystem: symmetrise from the lower triangle, :176-182
+    for (int i = 0; i < Nd; ++i)
+        for (int j = i + 1; j < Nd; ++j)
+            K[static_cast< size_t >(i) * Nd + j] = K[static_cast< size_t >(j) * Nd + i];
+    return 0;
+}
+
+int orc_apply_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                    const double* kparams, double time, const double* x, double* y)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const int      N = rb.N, Nd = N * U;
+    KernelEval     ke{k, R};
+    QpData         qd;
+    std::vector< double > scratch, block(static_cast< size_t >(U) * E), Bt(static_cast< size_t >(Nd) * E), tx(E);
+    std::fill(y, y + static_cast< size_t >(Nd) * R, 0.);
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
+        if (!(qd.jac > 0.))
+            return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // EvaluateLocalOperator.hpp:229
+        const double w = qd.jac * rb.weights[qi];
+        // fillBatch (:96-127): B_q^T, Nd x E
+        for (int b = 0; b < N; ++b)
+        {
+            basisBlock(ke, dim, E, U, rb.vals[static_cast< size_t >(qi) * N + b], qd.phys.data(), N, b, block.data());
+            for (int u = 0; u < U; ++u)
+                for (int e = 0; e < E; ++e)
+                    Bt[static_cast< size_t >(b * U + u) * E + e] = block[u * E + e];
+        }
+        // flushImpl (:130-146): per rhs two GEMVs with the weights in between
+        for (int r = 0; r < R; ++r)
+        {
+            for (int e = 0; e < E; ++e)
+            {
+                double acc = 0.;
+                for (int i = 0; i < Nd; ++i)
+                    acc += Bt[static_cast< size_t >(i) * E + e] * x[i + static_cast< size_t >(Nd) * r];
+                tx[e] = acc * w;
+            }
+            for (int i = 0; i < Nd; ++i)
+            {
+                double acc = 0.;
+                for (int e = 0; e < E; ++e)
+                    acc += Bt[static_cast< size_t >(i) * E + e] * tx[e];
+                y[i + static_cast< size_t >(Nd) * r] += acc;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                       const double* kparams, double time, int n_dir, const int* dir_inds, const double* dir_vals,
+                       double* diag, double* rhs)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const int      N = rb.N, Nd = N * U;
+    KernelEval     ke{k, R};
+    QpData         qd;
+    std::vector< double > scratch, block(static_cast< size_t >(U) * E), Bt(static_cast< size_t >(Nd) * E),
+        inter(static_cast< size_t >(E) * R);
+    std::fill(diag, diag + Nd, 0.);
+    std::fill(rhs, rhs + static_cast< size_t >(Nd) * R, 0.);
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
+        if (!(qd.jac > 0.))
+            return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // EvaluateLocalOperator.hpp:295
+        const double w = qd.jac * rb.weights[qi];
+        // precomputeDiagRhsImpl, EvaluateLocalOperator.hpp:172-208
+        for (int b = 0; b < N; ++b)
+        {
+            basisBlock(ke, dim, E, U, rb.vals[static_cast< size_t >(qi) * N + b], qd.phys.data(), N, b, block.data());
+            for (int u = 0; u < U; ++u)
+            {
+                double sq = 0.;
+                for (int e = 0; e < E; ++e)
+                {
+                    sq += block[u * E + e] * block[u * E + e];
+                    Bt[static_cast< size_t >(b * U + u) * E + e] = block[u * E + e];
+                }
+                diag[b * U + u] += sq * w; // :186
+                for (int r = 0; r < R; ++r)
+                {
+                    double acc = 0.;
+                    for (int e = 0; e < E; ++e)
+                        acc += block[u * E + e] * ke.out.rhs[e * R + r];
+                    rhs[(b * U + u) + static_cast< size_t >(Nd) * r] += acc * w; // :187
+                }
+            }
+        }
+        if (n_dir > 0) // :195-207
+        {
+            for (int e = 0; e < E; ++e)
+                for (int r = 0; r < R; ++r)
+                {
+                    double acc = 0.;
+                    for (int i = 0; i < n_dir; ++i)
+                        acc += Bt[static_cast< size_t >(dir_inds[i]) * E + e] * dir_vals[i + static_cast< size_t >(n_dir) * r];
+                    inter[e * R + r] = acc * w;
+                }
+            for (int i = 0; i < Nd; ++i)
+                for (int r = 0; r < R; ++r)
+                {
+                    double acc = 0.;
+                    for (int e = 0; e < E; ++e)
+                        acc += Bt[static_cast< size_t >(i) * E + e] * inter[e * R + r];
+                    rhs[i + static_cast< size_t >(Nd) * r] -= acc;
+                }
+        }
+    }
+    return 0;
+}
+
+int orc_apply_sumfact(int kernel_id, int p, int nq, int R, int odd_even, int pass_true_z, const double* verts,
+                      const double* node_fields, const double* kparams, double time, const double* x, double* y)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const SumFactCtx ctx{k, p, nq, R, odd_even != 0, pass_true_z != 0};
+    const int        N = ipow(p + 1, dim), Nd = N * U, nops = U * R;
+    // x_gather layout: col-major [node][u + U*rhs], fields appended (SumFactorization.hpp:901-909,
+    // tests/LocalOperatorCommon.hpp:150-157)
+    std::vector< double > fill(static_cast< size_t >(N) * (nops + F)), res(static_cast< size_t >(N) * nops);
+    for (int n = 0; n < N; ++n)
+    {
+        for (int r = 0; r < R; ++r)
+            for (int u = 0; u < U; ++u)
+                fill[n + static_cast< size_t >(N) * (r * U + u)] = x[(n * U + u) + static_cast< size_t >(Nd) * r];
+        for (int f = 0; f < F; ++f)
+            fill[n + static_cast< size_t >(N) * (nops + f)] = node_fields[n * F + f];
+    }
+    sumFactElement(ctx, verts, fill.data(), kparams, time, res.data());
+    // y_scatter layout: row-major [node][u + U*rhs] (tests/LocalOperatorCommon.hpp:158-166)
+    for (int n = 0; n < N; ++n)
+        for (int r = 0; r < R; ++r)
+            for (int u = 0; u < U; ++u)
+                y[(n * U + u) + static_cast< size_t >(Nd) * r] = res[static_cast< size_t >(n) * nops + r * U + u];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int orc_mf_apply(const orc_mesh* m, int kernel_id, const double* kparams, double time, int odd_even, int ncols,
+                 const double* x, size_t ldx, double* y, size_t ldy, double alpha, double beta, int64_t e_begin,
+                 int64_t e_end, int do_scale, int do_dirichlet_rows, int64_t n_owned_dofs, int nthreads)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    if (dim != m->dim)
+        return fail(-1, "kernel / mesh dimension mismatch");
+    const int     R = ncols, N = ipow(m->p + 1, dim), nv = 1 << dim, nops = U * R, dpn = m->dofs_per_node;
+    const int64_t n_local_dofs = m->n_local_nodes * dpn;
+    if (do_scale) // MatrixFreeSystem.hpp:1038
+        for (int r = 0; r < R; ++r)
+            for (int64_t i = 0; i < n_local_dofs; ++i)
+                y[i + ldy * r] = beta == 0. ? 0. : y[i + ldy * r] * beta;
+    const SumFactCtx ctx{k, m->p, m->nq, R, odd_even != 0, true};
+    const bool       atomic = nthreads > 1;
+    parallelFor(e_begin, e_end, nthreads, [&](int64_t b, int64_t e, int) {
+        std::vector< double > fill(static_cast< size_t >(N) * (nops + F)), res(static_cast< size_t >(N) * nops);
+        for (int64_t el = b; el < e; ++el)
+        {
+            const uint32_t* nodes = m->elem_nodes + el * N;
+            // gatherSumFact, MatrixFreeSystem.hpp:421-467 (getDofs :298-311)
+            for (int n = 0; n < N; ++n)
+            {
+                for (int u = 0; u < U; ++u)
+                {
+                    const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                    const bool    dir = m->dirichlet && m->dirichlet[dof];
+                    for (int r = 0; r < R; ++r)
+                        fill[n + static_cast< size_t >(N) * (r * U + u)] = dir ? 0. : x[dof + ldx * r];
+                }
+                for (int f = 0; f < F; ++f) // FieldAccess::fill, post/FieldAccess.hpp:21-30
+                    fill[n + static_cast< size_t >(N) * (nops + f)] = m->fields[f * m->n_local_nodes + nodes[n]];
+            }
+            sumFactElement(ctx, m->elem_verts + el * nv * 3, fill.data(), kparams, time, res.data());
+            // scatterSumFact, MatrixFreeSystem.hpp:494-537
+            for (int n = 0; n < N; ++n)
+                for (int u = 0; u < U; ++u)
+                {
+                    const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                    if (m->dirichlet && m->dirichlet[dof])
+                        continue;
+                    for (int r = 0; r < R; ++r)
+                        atomicAdd(y[dof + ldy * r], res[static_cast< size_t >(n) * nops + r * U + u] * alpha, atomic);
+                }
+        }
+    });
+    if (do_dirichlet_rows && m->dirichlet) // MatrixFreeSystem.hpp:1087-1098
+        for (int64_t d = 0; d < n_owned_dofs; ++d)
+            if (m->dirichlet[d])
+                for (int r = 0; r < R; ++r)
+                    y[d + ldy * r] += x[d + ldx * r] * alpha;
+    return 0;
+}
+
+int orc_mf_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, double time, int R,
+                    const double* dirichlet_vals, size_t ldg, double* diag, double* rhs, size_t ldr,
+                    int64_t e_begin, int64_t e_end, int finalize, int64_t n_owned_dofs, int nthreads)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k)
+        return fail(-1, "unknown kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const int  N = ipow(m->p + 1, dim), nv = 1 << dim, Nd = N * U, dpn = m->dofs_per_node;
+    const bool atomic = nthreads > 1;
+    std::atomic< int > status{0};
+    parallelFor(e_begin, e_end, nthreads, [&](int64_t b, int64_t e, int) {
+        std::vector< double > nf(static_cast< size_t >(N) * std::max(F, 1)), ldiag(Nd), lrhs(static_cast< size_t >(Nd) * R),
+            dvals;
+        std::vector< int > dinds;
+        for (int64_t el = b; el < e; ++el)
+        {
+            const uint32_t* nodes = m->elem_nodes + el * N;
+            dinds.clear();
+            for (int n = 0; n < N; ++n)
+            {
+                for (int f = 0; f < F; ++f)
+                    nf[n * F + f] = m->fields[f * m->n_local_nodes + nodes[n]];
+                for (int u = 0; u < U; ++u)
+                {
+                    const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                    if (m->dirichlet && m->dirichlet[dof])
+                        dinds.push_back(n * U + u);
+                }
+            }
+            const int nd = static_cast< int >(dinds.size());
+            dvals.assign(static_cast< size_t >(nd) * R, 0.);
+            for (int i = 0; i < nd; ++i) // gatherDirichletVals, MatrixFreeSystem.hpp:364-375
+            {
+                const int64_t dof = static_cast< int64_t >(nodes[dinds[i] / U]) * dpn + m->field_inds[dinds[i] % U];
+                for (int r = 0; r < R; ++r)
+                    dvals[i + static_cast< size_t >(nd) * r] = dirichlet_vals ? dirichlet_vals[dof + ldg * r] : 0.;
+            }
+            const int rc = orc_diag_rhs_local(kernel_id, m->p, m->nq, R, m->elem_verts + el * nv * 3, nf.data(), kparams,
+                                              time, nd, dinds.data(), dvals.data(), ldiag.data(), lrhs.data());
+            if (rc)
+            {
+                status = rc;
+                return;
+            }
+            // scatterInit, MatrixFreeSystem.hpp:377-390
+            for (int n = 0; n < N; ++n)
+                for (int u = 0; u < U; ++u)
+                {
+                    const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                    atomicAdd(diag[dof], ldiag[n * U + u], atomic);
+                    for (int r = 0; r < R; ++r)
+                        atomicAdd(rhs[dof + ldr * r], lrhs[(n * U + u) + static_cast< size_t >(Nd) * r], atomic);
+                }
+        }
+    });
+    if (status)
+        return status;
+    if (finalize && m->dirichlet) // MatrixFreeSystem.hpp:911-915
+        for (int64_t d = 0; d < n_owned_dofs; ++d)
+            if (m->dirichlet[d])
+            {
+                diag[d] = 1.;
+                for (int r = 0; r < R; ++r)
+                    rhs[d + ldr * r] = dirichlet_vals ? dirichlet_vals[d + ldg * r] : 0.;
+            }
+    return 0;
+}
+} // extern "C"

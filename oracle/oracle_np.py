@@ -1,0 +1,237 @@
+"""Independent numpy/mpmath restatement of the L3STER element-local formulas.  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Purpose: a second, structurally different statement of the same mathematics (dense B_q matrices built with einsum,
+tables from mpmath at 50 digits) used to (a) cross-check oracle/oracle.cpp and (b) generate the golden fixtures under
+tests/golden/ (oracle/make_golden.py).  It follows the reference's definitions, cited as file:line under
+/root/reference:
+
+  K_e = sum_q w_q detJ_q B_q^T B_q,  F_e = sum_q w_q detJ_q B_q^T f_q        algsys/AssembleLocalSystem.hpp:131-166
+  B_q[:, b*U+u] = A0[:,u] phi_b + sum_d A_d[:,u] d_d phi_b                    algsys/AssembleLocalSystem.hpp:131-142
+  y_e = K_e x_e                                                               algsys/EvaluateLocalOperator.hpp:130-146
+  diag = diag(K_e), rhs = F_e - K_e[:, D] g_D                                 algsys/EvaluateLocalOperator.hpp:172-208
+  phi_b tensor Lagrange on GLL nodes, b = ix + n(iy + n iz)                   basisfun/ReferenceBasisFunction.hpp:74-153
+  J[d][s] = d x_s / d xi_d from the 2^dim vertices, grad phi = J^{-1} grad_ref phi   mapping/JacobiMat.hpp:15-45,
+                                                                               mapping/ComputePhysBasisDer.hpp:9-15
+"""
+import numpy as np
+
+try:
+    import mpmath as mp
+    mp.mp.dps = 50
+except ImportError:  # pragma: no cover
+    mp = None
+
+
+# ---------------------------------------------------------------- tables (mpmath, 50 digits)
+def _legendre_roots(n, derivative=False):
+    """Roots of P_n (or of P_n') ascending: double-precision guesses from numpy's Legendre series (companion-matrix
+    eigenvalues, the reference's own route, math/Polynomial.hpp:98-122) polished to 50 digits by mp.findroot."""
+    series = np.polynomial.legendre.Legendre.basis(n)
+    guesses = np.sort((series.deriv() if derivative else series).roots().real)
+    if derivative:
+        f = lambda x: mp.diff(lambda t: mp.legendre(n, t), x)
+    else:
+        f = lambda x: mp.legendre(n, x)
+    roots = sorted(mp.findroot(f, mp.mpf(float(g))) for g in guesses)
+    assert all(abs(float(r) - g) < 1e-10 for r, g in zip(roots, guesses))
+    return roots
+
+
+def gll_nodes_mp(n):
+    if n == 2:
+        return [mp.mpf(-1), mp.mpf(1)]
+    return [mp.mpf(-1)] + _legendre_roots(n - 1, derivative=True) + [mp.mpf(1)]
+
+
+def gl_rule_mp(nq):
+    xs = _legendre_roots(nq)
+    ws = []
+    for x in xs:
+        dP = mp.diff(lambda t: mp.legendre(nq, t), x)
+        ws.append(2 / ((1 - x * x) * dP * dP))
+    return xs, ws
+
+
+def lagrange_mp(nodes, x):
+    n = len(nodes)
+    vals, ders = [], []
+    for b in range(n):
+        den = mp.mpf(1)
+        for j in range(n):
+            if j != b:
+                den *= nodes[b] - nodes[j]
+        v = mp.mpf(1)
+        for j in range(n):
+            if j != b:
+                v *= x - nodes[j]
+        d = mp.mpf(0)
+        for k in range(n):
+            if k == b:
+                continue
+            pr = mp.mpf(1)
+            for j in range(n):
+                if j != b and j != k:
+                    pr *= x - nodes[j]
+            d += pr
+        vals.append(v / den)
+        ders.append(d / den)
+    return vals, ders
+
+
+def tables(p, nq):
+    """gll[n], qx[nq], qw[nq], I[n,nq], D[n,nq] as float64 (rounded from 50-digit values)."""
+    gll = gll_nodes_mp(p + 1)
+    qx, qw = gl_rule_mp(nq)
+    I = np.zeros((p + 1, nq))
+    D = np.zeros((p + 1, nq))
+    for q, x in enumerate(qx):
+        v, d = lagrange_mp(gll, x)
+        I[:, q] = [float(t) for t in v]
+        D[:, q] = [float(t) for t in d]
+    f = lambda a: np.array([float(t) for t in a])
+    return f(gll), f(qx), f(qw), I, D
+
+
+# ---------------------------------------------------------------- kernels (restated; ids as oracle.h)
+def kernel_params(kid):
+    return {0: (3, 7, 4, 0), 1: (3, 7, 4, 1), 2: (2, 4, 3, 0), 3: (2, 4, 3, 1), 4: (3, 7, 4, 3)}[kid]
+
+
+def eval_kernel(kid, fv, fd, R, kparams=None):
+    """Returns A [D+1,E,U], rhs [E,R].  tests/Kernels.hpp:5-118, benchmarks/Diffusion3D.hpp:51-79."""
+    dim, E, U, F = kernel_params(kid)
+    A = np.zeros((dim + 1, E, U))
+    rhs = np.zeros((E, R))
+    if kid in (0, 1, 4):
+        if kid == 0:
+            k, s = (1.0, 1.0) if kparams is None else kparams[:2]
+            lam = k
+            rhs[0, 0] = s
+        elif kid == 1:
+            lam = fv[0]
+            A[0, 0, 1:4] = [-fd[0][0], -fd[1][0], -fd[2][0]]
+        else:
+            k, sigma, s = (1.0, 1.0, 1.0) if kparams is None else kparams[:3]
+            lam = k
+            A[0, 0, 0] = sigma
+            A[1, 0, 0], A[2, 0, 0], A[3, 0, 0] = fv[0], fv[1], fv[2]
+            rhs[0, 0] = s
+        A[1, 0, 1] = A[2, 0, 2] = A[3, 0, 3] = -lam
+        for d in (1, 2, 3):
+            A[0, d, d] = -1.0
+            A[d, d, 0] = 1.0
+        A[2, 4, 3], A[3, 4, 2] = 1.0, -1.0
+        A[1, 5, 3], A[3, 5, 1] = -1.0, 1.0
+        A[1, 6, 2], A[2, 6, 1] = 1.0, -1.0
+    else:
+        lam = 1.0 if kid == 2 else fv[0]
+        if kid == 3:
+            A[0, 0, 1], A[0, 0, 2] = -fd[0][0], -fd[1][0]
+        A[1, 0, 1] = A[2, 0, 2] = -lam
+        A[0, 1, 1] = A[0, 2, 2] = -1.0
+        A[1, 1, 0] = A[2, 2, 0] = 1.0
+        A[1, 3, 2], A[2, 3, 1] = 1.0, -1.0
+    return A, rhs
+
+
+# ---------------------------------------------------------------- element operators (dense)
+def _lin(x):
+    return np.array([0.5 * (1 - x), 0.5 * (1 + x)]), np.array([-0.5, 0.5])
+
+
+def jacobi(dim, verts, pt):
+    """J[d, s]"""
+    v, d = zip(*[_lin(pt[a]) for a in range(dim)])
+    J = np.zeros((dim, dim))
+    for vi in range(2 ** dim):
+        idx = [(vi >> a) & 1 for a in range(dim)]
+        for dd in range(dim):
+            sf = 1.0
+            for a in range(dim):
+                sf *= d[a][idx[a]] if a == dd else v[a][idx[a]]
+            J[dd, :] += verts[vi, :dim] * sf
+    return J
+
+
+def phys_point(dim, verts, pt):
+    v = [_lin(pt[a])[0] for a in range(dim)]
+    out = np.zeros(3)
+    for vi in range(2 ** dim):
+        sf = 1.0
+        for a in range(dim):
+            sf *= v[a][(vi >> a) & 1]
+        out += verts[vi] * sf
+    return out
+
+
+def element_B(kid, p, nq, R, verts, node_fields=None, kparams=None):
+    """Returns B [nqp, E, Nd], w*detJ [nqp], f [nqp, E, R]; QP order x fastest (order is irrelevant to the sums)."""
+    dim, E, U, F = kernel_params(kid)
+    verts = np.asarray(verts, dtype=np.float64)
+    gll, qx, qw, I, D = tables(p, nq)
+    n = p + 1
+    N = n ** dim
+    nqp = nq ** dim
+    B = np.zeros((nqp, E, N * U))
+    wj = np.zeros(nqp)
+    fq = np.zeros((nqp, E, R))
+    for qi in range(nqp):
+        q = [(qi // nq ** a) % nq for a in range(dim)]
+        pt = [qx[q[a]] for a in range(dim)]
+        # tensor basis values / reference derivatives, b = ix + n*(iy + n*iz)
+        phi = np.ones(N)
+        dphi = np.ones((dim, N))
+        for b in range(N):
+            bi = [(b // n ** a) % n for a in range(dim)]
+            for a in range(dim):
+                phi[b] *= I[bi[a], q[a]]
+                for dd in range(dim):
+                    dphi[dd, b] *= D[bi[a], q[a]] if a == dd else I[bi[a], q[a]]
+        J = jacobi(dim, verts, pt)
+        gphi = np.linalg.solve(J, dphi)  # J^{-1} grad_ref
+        fv = np.zeros(F)
+        fd = np.zeros((dim, F))
+        if F:
+            fv = node_fields.T @ phi
+            fd = gphi @ node_fields
+        A, rhs = eval_kernel(kid, fv, fd, R, kparams)
+        Bq = np.einsum("eu,b->ebu", A[0], phi)
+        for dd in range(dim):
+            Bq += np.einsum("eu,b->ebu", A[dd + 1], gphi[dd])
+        B[qi] = Bq.reshape(E, N * U)
+        w = 1.0
+        for a in range(dim):
+            w *= qw[q[a]]
+        wj[qi] = w * np.linalg.det(J)
+        fq[qi] = rhs
+    return B, wj, fq
+
+
+def assemble(kid, p, nq, R, verts, node_fields=None, kparams=None):
+    B, wj, fq = element_B(kid, p, nq, R, verts, node_fields, kparams)
+    nqp, E, Nd = B.shape
+    Bw = (B * wj[:, None, None]).reshape(nqp * E, Nd)
+    K = Bw.T @ B.reshape(nqp * E, Nd)
+    Fe = Bw.T @ fq.reshape(nqp * E, R)
+    return K, Fe
+
+
+def node_locations(dim, p, verts):
+    gll = tables(p, p + 1)[0]
+    n = p + 1
+    out = np.zeros((n ** dim, 3))
+    for b in range(n ** dim):
+        pt = [gll[(b // n ** a) % n] for a in range(dim)]
+        out[b] = phys_point(dim, np.asarray(verts, dtype=np.float64), pt)
+    return out
+
+
+def boundary_nodes(dim, p):
+    """Local indices of nodes on the element boundary (mesh/ElementTraits.hpp boundary_node_inds), ascending."""
+    n = p + 1
+    out = []
+    for b in range(n ** dim):
+        bi = [(b // n ** a) % n for a in range(dim)]
+        if any(i in (0, n - 1) for i in bi):
+            out.append(b)
+    return np.array(out)
