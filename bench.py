@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- DOF/s of the matrix-free sum-factorised Diffusion3D operator apply (hex, order 6) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ne 64] [--order 6]
+
+A "step" is one operator apply Y <- A X (alpha = 1, beta = 0) over the whole mesh.  Workload per GPU (weak scaling):
+a 64^3-element block of order-6 hexes on [0,1]^3 (228.3 M global dofs on one GPU; 128^3 = BASELINE.json config 3 on
+8 GPUs as 2x2x2 blocks), smoothly perturbed vertices (no affine shortcut), Dirichlet on unknown 0 of all six sides,
+kernel = benchmarks/Diffusion3D.hpp:51-79 (U = 4, E = 7, k = s = 1), x ~ U(-1,1) synthetic, resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and (N = 1) `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from l3ster_amd import system  # noqa: E402
+from l3ster_amd.distributed import DistributedOperator, HaloPlan  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+
+
+def algorithmic_bytes_per_dof(p, U, F=0):
+    """read x 8 B + write y 8 B + connectivity 4*npe/(p^3 U) + vertices 192/(p^3 U) (+ 8F/U)."""
+    npe = (p + 1) ** 3
+    return 16.0 + (4.0 * npe + 192.0) / (p ** 3 * U) + 8.0 * F / U
+
+
+def cpu_baseline(p, U, seconds_target=15.0):
+    """The CPU oracle (port of the reference algorithm: per-element gather, sum-factorised sweeps in the reference's
+    order, atomic scatter, element loop over all host threads) timed on a bounded sample of the same workload."""
+    import oracle_lib as O
+    from helpers import oracle_mesh
+    so = "/tmp/liboracle_native.so"
+    try:
+        O.build(so, march="native")
+        L = O.lib(so)
+        flavour = "-O3 -march=native"
+    except Exception:  # pragma: no cover - fall back to the prebuilt x86-64-v3 library
+        L = O.lib()
+        flavour = "-O3 -march=x86-64-v3"
+    cores = os.cpu_count() or 1
+    ne = 8
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
+    x = np.asfortranarray(part.synthetic_vector(U).T)
+    y = np.zeros_like(x, order="F")
+    O.mf_apply(om, 0, x, y, nthreads=cores, L=L)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.mf_apply(om, 0, x, y, nthreads=cores, L=L)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_target or n >= 50:
+            break
+    dofs = part.n_global_nodes * U
+    return {"value": dofs * n / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"{n} applies of the same kernel on a {ne}^3-element order-{p} block ({dofs} dofs), "
+                      f"oracle/oracle.cpp orc_mf_apply {flavour}, {cores} threads, {dt:.1f} s"}, (part, mask, x, y)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ne", type=int, default=64, help="elements per edge of each GPU's block")
+    ap.add_argument("--order", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.gpus not in PARTS:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    p, U, kid = args.order, 4, system.KERNEL_DIFFUSION3D
+    parts = PARTS[world]
+    ne_global = tuple(args.ne * q for q in parts)
+
+    t_setup = time.perf_counter()
+    part = system.CubePartition(ne_global, p, parts, rank, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    ctx = system.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, kid, [1.0, 1.0])
+    n_owned = part.n_owned_nodes * U
+    X = system.synthetic_vector_torch(part.node_grid_id[:part.n_owned_nodes], U, dev)
+    Y = torch.empty_like(X)
+    op = DistributedOperator(mf, HaloPlan(part, U, dev)) if world > 1 else None
+    t_setup = time.perf_counter() - t_setup
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if op is not None:
+            op.apply(X, Y, 1.0, 0.0)
+        elif i is None:
+            mf.apply(X, Y, 1.0, 0.0)
+        else:  # same three launches as l3k_mf_apply, with events around the element kernel
+            mf.scale(Y, 0.0)
+            ev0[i].record()
+            mf.apply_elems(2, X, None, Y, None, 1.0)
+            ev1[i].record()
+            mf.dirichlet_rows(X, Y, 1.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    global_dofs = part.n_global_nodes * U
+    value = global_dofs * args.steps / elapsed
+    bpd = algorithmic_bytes_per_dof(p, U)
+    result = {
+        "metric": "DOF/s for MF operator apply (Diffusion3D, hex p=6)" if p == 6 else f"DOF/s for MF operator apply (Diffusion3D, hex p={p})",
+        "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Diffusion3D matrix-free sum-factorised apply, hex mesh {ne_global[0]}x{ne_global[1]}x{ne_global[2]}, "
+                               f"order {p}, U=4 E=7, {global_dofs} global dofs, {args.ne}^3 elements per GPU, "
+                               f"partition {parts[0]}x{parts[1]}x{parts[2]}",
+                   "alpha": 1.0, "beta": 0.0, "setup_s": round(t_setup, 2)},
+    }
+    if rank == 0:
+        if world == 1:
+            ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+            alg_bytes = bpd * global_dofs
+            achieved = alg_bytes / (ms * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "kernel": "sumfactApplyKernel", "kernel_ms": ms, "bytes_per_dof": bpd,
+                                  "dofs_per_launch": global_dofs}
+            if not args.no_cpu_baseline:
+                base, (spart, smask, sx, sy) = cpu_baseline(p, U)
+                result["cpu_baseline"] = base
+                # the sample doubles as a live parity check of the GPU path against the oracle
+                smesh = system.DeviceMesh(ctx, spart, U, smask)
+                smf = system.MatrixFreeSystem(smesh, kid, [1.0, 1.0])
+                SX = torch.as_tensor(np.ascontiguousarray(sx.T), device=dev)
+                SY = torch.empty_like(SX)
+                smf.apply(SX, SY)
+                torch.cuda.synchronize()
+                err = np.linalg.norm(SY.cpu().numpy().T - sy) / np.linalg.norm(sy)
+                result["config"]["parity_vs_oracle_rel_l2"] = float(err)
+                if not err < 1e-11:
+                    raise SystemExit(f"GPU result differs from the oracle: rel L2 {err}")
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

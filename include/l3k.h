@@ -1,0 +1,192 @@
+/* l3k.h -- C ABI of the MI355X-native element-local hot path (libl3k.so).
+ *
+ * Drop-in boundary for the L3STER hot path.  The reference is header-only C++ with no FFI; each entry
+ * point below names the reference interface (file:line under /root/reference/include/l3ster) it stands in for.  Plain
+ * pointers and sizes only; never throws across the boundary: every function returns 0 on success, < 0 on error, and
+ * l3k_last_error() gives the text (the reference throws std::runtime_error from util::throwingAssert,
+ * util/Assertion.hpp:88-95).
+ *
+ * Pointer conventions: arguments named d_* are DEVICE pointers (HBM of the ctx's GPU); everything else is host memory.
+ * Vectors are column-major [row][col] with an explicit leading dimension, owned rows only, exactly like the host view
+ * of the Tpetra multivectors the reference's Operator::apply works on (algsys/ComputeValuesAtNodes.hpp:27-31,62-65).
+ * Calls on one l3k_ctx are serialised by the caller (the reference's apply is not re-entrant either: shared
+ * import/export buffers, algsys/MatrixFreeSystem.hpp:1008-1009).  All device work is enqueued on the ctx's HIP stream
+ * and is asynchronous with respect to the host unless stated otherwise.
+ */
+#ifndef L3K_H
+#define L3K_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L3K_VERSION 100
+
+typedef struct l3k_ctx      l3k_ctx;
+typedef struct l3k_mesh     l3k_mesh;
+typedef struct l3k_mf       l3k_mf;
+typedef struct l3k_hostmesh l3k_hostmesh;
+
+int         l3k_version(void);
+const char* l3k_last_error(void);
+
+/* ---- compile-time structs of the reference, as runtime descriptors ---------------------------------------------- */
+/* KernelParams, common/KernelInterface.hpp:13-20 */
+typedef struct
+{
+    int dimension, n_equations, n_unknowns, n_fields, n_rhs;
+} l3k_kparams;
+/* AssemblyOptions, algsys/AssembleLocalSystem.hpp:24-49.  eval_strategy: 0 Auto, 1 LocalElement, 2 SumFactorization,
+ * 3 SumFactorizationOddEvenDecomposition (LocalEvalStrategy, :16-22).  On the device every strategy runs the same
+ * sum-factorised kernel (collocation-derivative form, mathematically identical). */
+typedef struct
+{
+    int value_order, derivative_order, eval_strategy;
+} l3k_asmopts;
+
+/* ---- tables (host; no GPU needed) ------------------------------------------------------------------------------- */
+/* math::getLobattoRuleAbsc, math/LobattoRuleAbsc.hpp:30-35 */
+int l3k_gll_nodes(int n, double* x);
+/* quad::getReferenceQuadrature<GaussLegendre>, quad/ReferenceQuadrature.hpp:24-51 (nq = QO/2+1 points) */
+int l3k_gl_rule(int nq, double* x, double* w);
+/* AssemblyOptions::order + getRefQuadSize: nq1d = value_order*p + derivative_order*(p-1) + 1 */
+int l3k_n_qps1d(int p, int value_order, int derivative_order);
+/* interpolation_matrix / derivative_matrix, algsys/SumFactorization.hpp:25-65: row-major [p+1][nq] */
+int l3k_basis_1d(int p, int nq, double* I, double* D);
+/* collocation derivative matrix on the nq Gauss points: C[q'][q] = l_q'^GL '(x_q), row-major [nq][nq] (device algorithm
+ * table; D = I * C for nq >= p+1) */
+int l3k_colloc_deriv(int nq, double* C);
+
+/* ---- kernel registry ------------------------------------------------------------------------------------------------
+ * The reference takes the operator definition as a C++ callable wrapped by wrapDomainEquationKernel<params>
+ * (common/KernelInterface.hpp:178-183) and instantiates the element loops on its type.  Here kernels are
+ * __host__ __device__ functors with the same (in, out) signature (include/l3k/kernel_interface.hpp), registered in
+ * l3ster_amd/csrc/user_kernels.hpp and instantiated into the HIP templates at build time; they are selected by id and
+ * carry an optional POD parameter block. */
+enum
+{
+    L3K_KERNEL_DIFFUSION3D     = 0, /* benchmarks/Diffusion3D.hpp:51-79; params {double k, s}                        */
+    L3K_KERNEL_DIFFUSION3D_VAR = 1, /* tests/Kernels.hpp:84-118, n_fields = 1                                          */
+    L3K_KERNEL_ADVDIFF3D       = 4  /* config-5 synthetic; params {double k, sigma, s}, n_fields = 3 */
+};
+int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_t* param_bytes);
+/* number of (kernel, order, nq, ncols) device instantiations, and the i-th one: for "is this shape built?" queries */
+int l3k_instance_count(void);
+int l3k_instance_info(int i, int* kernel_id, int* order, int* nq, int* ncols);
+
+/* ---- context ----------------------------------------------------------------------------------------------------- */
+/* One ctx per GPU / per process.  hip_stream is a hipStream_t (NULL = default stream); torch users pass
+ * torch.cuda.current_stream().cuda_stream. */
+int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out);
+int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream);
+int l3k_ctx_synchronize(l3k_ctx* ctx);
+int l3k_ctx_destroy(l3k_ctx* ctx);
+
+/* ---- device mesh --------------------------------------------------------------------------------------------------
+ * What the reference keeps in LocalMeshView / LocalElementView (mesh/LocalMeshView.hpp:13-145), LocalDofMap
+ * (dofs/NodeToDofMap.hpp:84-109) and LocalDirichletBC (bcs/LocalDirichletBC.hpp:13-32), flattened.  Uploaded once. */
+typedef struct
+{
+    int             dim;            /* 3 (hex)                                                                      */
+    int             order;          /* p; nodes per element N = (p+1)^dim, lexicographic, xi fastest               */
+    int64_t         n_elems;        /* elements [0, n_interior_elems) touch owned dofs only, the rest are "border" */
+    int64_t         n_interior_elems; /* splitBorderAndInterior, algsys/MatrixFreeSystem.hpp:969-981              */
+    const uint32_t* elem_nodes;     /* [n_elems][N] local node ids (n_loc_id_t, common/Typedefs.h:14)              */
+    const double*   elem_verts;     /* [n_elems][2^dim][3], vertex v = i + 2j + 4k (mesh/primitives/CubeMesh.hpp)  */
+    int64_t         n_owned_nodes;  /* local node numbering: owned first, then ghosts (LocalMeshView.hpp:425-458)  */
+    int64_t         n_ghost_nodes;
+    int             dofs_per_node;  /* dof(node,k) = node*dofs_per_node + k (dofs/NodeToDofMap.hpp:250-264)        */
+    const uint8_t*  dirichlet;      /* [(n_owned+n_ghost)*dofs_per_node] byte mask or NULL (isDirichletDof)       */
+} l3k_mesh_desc;
+int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* desc, l3k_mesh** out);
+int l3k_mesh_destroy(l3k_mesh* mesh);
+
+/* ---- matrix-free operator ------------------------------------------------------------------------------------------
+ * Stands in for algsys::MatrixFreeSystem (assembleProblem + Operator::apply), algsys/MatrixFreeSystem.hpp:24-89.
+ * field_inds[n_unknowns]: which per-node dof each unknown maps to (detail::getDofs, :298-311). */
+int l3k_mf_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kparam_blob, size_t kparam_bytes,
+                  const l3k_asmopts* opts, const int* field_inds, int n_rhs, l3k_mf** out);
+int l3k_mf_destroy(l3k_mf* mf);
+/* external fields read by the kernel: SoA [n_fields][ld] over local nodes, value(node, f) = d_soa[node + f*ld]
+ * (post::FieldAccess, post/FieldAccess.hpp:21-30).  The pointer is kept, not copied. */
+int l3k_mf_set_fields(l3k_mf* mf, const double* d_soa, size_t ld);
+int l3k_mf_set_time(l3k_mf* mf, double time);
+
+/* Y <- alpha*A*X + beta*Y.  Operator::apply / applyImpl, algsys/MatrixFreeSystem.hpp:34-41,1020-1140, for a rank
+ * without ghosts (n_ghost_nodes == 0): scale (:1038), gather with Dirichlet -> 0 (:421-467), sum-factorised element
+ * kernel (algsys/SumFactorization.hpp:882-917), scatter-add skipping Dirichlet dofs (:494-537), y[d] += alpha*x[d] on
+ * owned Dirichlet rows (:1087-1098).  ncols <= n_rhs, else error (:1035-1037). */
+int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha,
+                 double beta);
+
+/* Split-phase form for ranks with ghosts (the pieces applyImpl interleaves with comm::Import/Export,
+ * algsys/MatrixFreeSystem.hpp:1046-1111).  Ghost values live in separate [n_ghost_dofs][ncols] buffers exactly like
+ * m_import_shared_buf / m_export_shared_buf (:1008-1009), accessed through BorderAccessor semantics
+ * (algsys/ComputeValuesAtNodes.hpp:21-50): local dof < n_owned -> owned vector, else ghost buffer.
+ *   which: 0 = interior elements, 1 = border elements, 2 = all. */
+int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta);                /* :1038           */
+int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg,
+                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha);
+int l3k_mf_dirichlet_rows(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols,
+                          double alpha);                                                        /* :1087-1098      */
+/* comm::Import pack (owner side gathers owned rows through m_owned_inds, comm/ImportExport.hpp:356-372) and
+ * comm::Export unpack-add (util::AtomicSumInto through m_owned_inds, :448-470), on DOF rows:
+ *   pack:       d_dst[i + n*c]  = d_src[idx[i] + ld*c]
+ *   unpack_add: d_dst[idx[i] + ld*c] += d_src[i + n*c]      (idx must not repeat within one call)                  */
+int l3k_pack_rows(l3k_ctx* ctx, const double* d_src, size_t ld, int ncols, const int32_t* d_idx, int64_t n,
+                  double* d_dst);
+int l3k_unpack_add_rows(l3k_ctx* ctx, const double* d_src, int64_t n, const int32_t* d_idx, double* d_dst, size_t ld,
+                        int ncols);
+
+/* diag(A) and rhs with Dirichlet lifting: computeDiagAndRhs, algsys/MatrixFreeSystem.hpp:888-941 around
+ * precomputeOperatorDiagonalAndRhs (algsys/EvaluateLocalOperator.hpp:172-208,276-301).  d_dirichlet_vals
+ * [n_local_dofs][n_rhs] (ld) or NULL (= 0); outputs accumulate into owned rows d_diag[n_owned_dofs],
+ * d_rhs[n_owned_dofs][n_rhs] and ghost rows d_diag_ghost / d_rhs_ghost (may be NULL when n_ghost_nodes == 0);
+ * the caller zeroes them first (:921-923).  finalize != 0 sets diag = 1, rhs = g on owned Dirichlet rows (:911-915). */
+int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
+                    size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg, int finalize);
+
+/* ---- LocalAssembly --------------------------------------------------------------------------------------------------
+ * assembleLocalSystem for a batch of elements, algsys/AssembleLocalSystem.hpp:234-256: K_e row-major [Nd][Nd],
+ * F_e column-major [Nd][n_rhs] per element, elements [first, first+count).  d_K may be NULL (then only the checksum
+ * below is produced); d_checksum[count] receives sum_ij K_e[i][j]*(1 + ((i*31 + j*17) % 7)) (streaming mode,
+ * SURVEY.md §0 D6). */
+int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum);
+
+/* ---- host-side synthetic mesh + block partition --------------------------------------------------------------------
+ * Stand-in for makeCubeMesh + convertMeshToOrder + partitionMesh + the ownership / import-export context
+ * (mesh/primitives/CubeMesh.hpp:16-138, mesh/ConvertMeshToOrder.hpp:51-104, mesh/PartitionMesh.hpp:142-183,
+ * util/SegmentedOwnership.hpp:11-45, comm/ImportExport.hpp:29-72) for structured hex cubes: ne[3] elements per edge
+ * on [0,1]^3, order p, parts[3] blocks, this rank's block `rank` = bx + parts[0]*(by + parts[1]*bz).
+ * perturb: vertices moved by perturb*h*sin(2 pi x)sin(2 pi y)sin(2 pi z).  Host only, no GPU. */
+int l3k_cube_partition_create(const int ne[3], int order, const int parts[3], int rank, double perturb,
+                              l3k_hostmesh** out);
+int l3k_hostmesh_destroy(l3k_hostmesh* hm);
+typedef struct
+{
+    int             dim, order;
+    int64_t         n_elems, n_interior_elems;
+    int64_t         n_owned_nodes, n_ghost_nodes;
+    int64_t         global_node_base;      /* first global node id owned by this rank (contiguous ownership)        */
+    int64_t         n_global_nodes;
+    const uint32_t* elem_nodes;            /* [n_elems][N], interior elements first                                  */
+    const double*   elem_verts;            /* [n_elems][8][3]                                                        */
+    const int64_t*  node_grid_id;          /* [n_owned+n_ghost] partition-independent id gx + NX*(gy + NY*gz)        */
+    const uint8_t*  node_boundary;         /* [n_owned+n_ghost] bit s set if the node lies on cube side s            */
+                                           /* sides: 0 z=0, 1 z=1, 2 y=0, 3 y=1, 4 x=0, 5 x=1 (ElementTraits.hpp:84-95) */
+    int             n_nbrs;                /* neighbours, ascending rank                                             */
+    const int*      nbr_rank;              /* [n_nbrs]                                                               */
+    const int64_t*  send_offsets;          /* [n_nbrs+1] into send_nodes: owned nodes each neighbour shares (import
+                                              send / export receive), ascending local id                             */
+    const int32_t*  send_nodes;
+    const int64_t*  ghost_offsets;         /* [n_nbrs+1] ghost-node ranges (relative to n_owned_nodes) owned by each
+                                              neighbour (import receive / export send); ghosts are sorted by global id */
+} l3k_hostmesh_view;
+int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

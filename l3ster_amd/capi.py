@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI declared in include/l3k.h (l3ster_amd/lib/libl3k.so).
+
+This is the reference-side binding a maintainer would write; it contains no compute.  The library
+must be present: there is no Python / CPU fallback for the device entry points.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libl3k.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint32_p = C.POINTER(C.c_uint32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class KParams(C.Structure):
+    _fields_ = [("dimension", C.c_int), ("n_equations", C.c_int), ("n_unknowns", C.c_int), ("n_fields", C.c_int),
+                ("n_rhs", C.c_int)]
+
+
+class AsmOpts(C.Structure):
+    _fields_ = [("value_order", C.c_int), ("derivative_order", C.c_int), ("eval_strategy", C.c_int)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("dim", C.c_int), ("order", C.c_int), ("n_elems", C.c_int64), ("n_interior_elems", C.c_int64),
+                ("elem_nodes", c_uint32_p), ("elem_verts", c_double_p), ("n_owned_nodes", C.c_int64),
+                ("n_ghost_nodes", C.c_int64), ("dofs_per_node", C.c_int), ("dirichlet", c_uint8_p)]
+
+
+class HostMeshView(C.Structure):
+    _fields_ = [("dim", C.c_int), ("order", C.c_int), ("n_elems", C.c_int64), ("n_interior_elems", C.c_int64),
+                ("n_owned_nodes", C.c_int64), ("n_ghost_nodes", C.c_int64), ("global_node_base", C.c_int64),
+                ("n_global_nodes", C.c_int64), ("elem_nodes", c_uint32_p), ("elem_verts", c_double_p),
+                ("node_grid_id", c_int64_p), ("node_boundary", c_uint8_p), ("n_nbrs", C.c_int), ("nbr_rank", c_int_p),
+                ("send_offsets", c_int64_p), ("send_nodes", c_int32_p), ("ghost_offsets", c_int64_p)]
+
+
+# every symbol include/l3k.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "l3k_version": (C.c_int, []),
+    "l3k_last_error": (C.c_char_p, []),
+    "l3k_gll_nodes": (C.c_int, [C.c_int, c_double_p]),
+    "l3k_gl_rule": (C.c_int, [C.c_int, c_double_p, c_double_p]),
+    "l3k_n_qps1d": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "l3k_basis_1d": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p]),
+    "l3k_colloc_deriv": (C.c_int, [C.c_int, c_double_p]),
+    "l3k_kernel_info": (C.c_int, [C.c_int, C.POINTER(KParams), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
+    "l3k_instance_count": (C.c_int, []),
+    "l3k_instance_info": (C.c_int, [C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "l3k_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "l3k_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "l3k_ctx_synchronize": (C.c_int, [_vp]),
+    "l3k_ctx_destroy": (C.c_int, [_vp]),
+    "l3k_mesh_create": (C.c_int, [_vp, C.POINTER(MeshDesc), C.POINTER(_vp)]),
+    "l3k_mesh_destroy": (C.c_int, [_vp]),
+    "l3k_mf_create": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), c_int_p, C.c_int,
+                                C.POINTER(_vp)]),
+    "l3k_mf_destroy": (C.c_int, [_vp]),
+    "l3k_mf_set_fields": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "l3k_mf_set_time": (C.c_int, [_vp, C.c_double]),
+    "l3k_mf_apply": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double, C.c_double]),
+    "l3k_mf_scale": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_double]),
+    "l3k_mf_apply_elems": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t,
+                                     C.c_int, C.c_double]),
+    "l3k_mf_dirichlet_rows": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double]),
+    "l3k_pack_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int64, _vp]),
+    "l3k_unpack_add_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, C.c_int]),
+    "l3k_mf_diag_rhs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, C.c_int]),
+    "l3k_local_assemble": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "l3k_cube_partition_create": (C.c_int, [c_int_p, C.c_int, c_int_p, C.c_int, C.c_double, C.POINTER(_vp)]),
+    "l3k_hostmesh_destroy": (C.c_int, [_vp]),
+    "l3k_hostmesh_view_get": (C.c_int, [_vp, C.POINTER(HostMeshView)]),
+}
+
+_lib = None
+
+
+class L3KError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libl3k.so; raises if it has not been built (python -m l3ster_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise L3KError(f"{LIB_PATH} is missing: build the HIP extension first (python -m l3ster_amd.build). "
+                       "There is no CPU fallback for the device path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise L3KError(f"libl3k error {rc}: {load().l3k_last_error().decode()}")

@@ -1,0 +1,723 @@
+// api.hip -- the extern "C" surface of libl3k.so (include/l3k.h) plus the small vector kernels around the element
+// kernels (scale, Dirichlet rows, pack / unpack-add).  No CPU fallback: without a usable HIP device every device entry
+// point fails with an error.
+#include "l3k.h"
+
+#include "device/common.hpp"
+#include "host/tables.hpp"
+#include "user_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <type_traits>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace l3k::dev
+{
+const char* lastError();
+}
+using l3k::dev::setError;
+
+#define L3K_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t err_ = (call);                                                                                \
+        if (err_ != hipSuccess)                                                                                        \
+        {                                                                                                              \
+            setError("%s failed: %s (%s:%d)", #call, hipGetErrorString(err_), __FILE__, __LINE__);                     \
+            return -3;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ small kernels
+namespace
+{
+// y <- beta*y (beta == 0: y <- 0, NaN-safe like putScalar(0.), algsys/MatrixFreeSystem.hpp:1038)
+__global__ void scaleKernel(double* __restrict__ y, size_t ld, int64_t rows, int ncols, double beta)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int c = 0; c < ncols; ++c)
+    {
+        double* col = y + ld * c;
+        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < rows; i += stride)
+            col[i] = beta == 0. ? 0. : col[i] * beta;
+    }
+}
+// y[d] += alpha*x[d] on owned Dirichlet rows (algsys/MatrixFreeSystem.hpp:1087-1098)
+__global__ void dirichletRowsKernel(const int64_t* __restrict__ rows, int64_t n, const double* __restrict__ x, size_t ldx,
+                                    double* __restrict__ y, size_t ldy, int ncols, double alpha)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const int64_t d = rows[i];
+        for (int c = 0; c < ncols; ++c)
+            y[d + ldy * c] += alpha * x[d + ldx * c];
+    }
+}
+// diag = 1, rhs = g on owned Dirichlet rows (algsys/MatrixFreeSystem.hpp:911-915)
+__global__ void dirichletFinalizeKernel(const int64_t* __restrict__ rows, int64_t n, const double* __restrict__ g, size_t ldg,
+                                        double* __restrict__ diag, double* __restrict__ rhs, size_t ldr, int ncols)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const int64_t d = rows[i];
+        diag[d]         = 1.;
+        for (int c = 0; c < ncols; ++c)
+            rhs[d + ldr * c] = g ? g[d + ldg * c] : 0.;
+    }
+}
+// comm::Import pack / comm::Export unpack (comm/ImportExport.hpp:356-372, 448-470)
+__global__ void packKernel(const double* __restrict__ src, size_t ld, int ncols, const int32_t* __restrict__ idx, int64_t n,
+                           double* __restrict__ dst)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const int64_t r = idx[i];
+        for (int c = 0; c < ncols; ++c)
+            dst[i + n * c] = src[r + ld * c];
+    }
+}
+__global__ void unpackAddKernel(const double* __restrict__ src, int64_t n, const int32_t* __restrict__ idx,
+                                double* __restrict__ dst, size_t ld, int ncols)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    {
+        const int64_t r = idx[i];
+        for (int c = 0; c < ncols; ++c)
+            dst[r + ld * c] += src[i + n * c];
+    }
+}
+inline unsigned gridFor(int64_t n, int block = 256)
+{
+    const int64_t g = (n + block - 1) / block;
+    return static_cast< unsigned >(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+template < typename T >
+struct DevBuf
+{
+    T*     ptr = nullptr;
+    size_t n   = 0;
+    DevBuf()   = default;
+    DevBuf(const DevBuf&)            = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+    }
+    int upload(const T* host, size_t count, hipStream_t s)
+    {
+        n = count;
+        if (count == 0)
+            return 0;
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ptr), count * sizeof(T)));
+        L3K_HIP(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+};
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ objects
+struct l3k_ctx
+{
+    int         device;
+    hipStream_t stream;
+};
+struct l3k_mesh
+{
+    l3k_ctx*            ctx;
+    int                 dim, order, dofs_per_node;
+    int64_t             n_elems, n_interior, n_owned_nodes, n_ghost_nodes;
+    DevBuf< uint32_t >  elem_nodes;
+    DevBuf< double >    elem_verts;
+    DevBuf< uint8_t >   dirichlet;
+    DevBuf< int64_t >   owned_dirichlet_rows;
+    int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
+    int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
+};
+struct l3k_mf
+{
+    l3k_ctx*            ctx;
+    l3k_mesh*           mesh;
+    int                 kernel_id, nq, n_rhs;
+    l3k_kparams         kp;
+    std::vector< char > blob;
+    int                 field_inds[l3k::dev::max_unknowns];
+    DevBuf< double >    tables;
+    const double*       fields = nullptr;
+    size_t              ldf    = 0;
+    double              time   = 0.;
+};
+
+namespace
+{
+struct KernelMeta
+{
+    int         id;
+    l3k_kparams kp;
+    const char* name;
+    size_t      bytes;
+};
+const std::vector< KernelMeta >& kernelMetas()
+{
+    static const std::vector< KernelMeta > metas = [] {
+        std::vector< KernelMeta > m;
+#define L3K_X(id, T, name)                                                                                             \
+    m.push_back({id, {T::params.dimension, T::params.n_equations, T::params.n_unknowns, T::params.n_fields, T::params.n_rhs}, \
+                 name, std::is_empty_v< T > ? size_t{0} : sizeof(T)});
+        L3K_FOR_EACH_KERNEL(L3K_X)
+#undef L3K_X
+        return m;
+    }();
+    return metas;
+}
+const KernelMeta* findKernel(int id)
+{
+    for (const auto& k : kernelMetas())
+        if (k.id == id)
+            return &k;
+    return nullptr;
+}
+
+int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
+{
+    const l3k_mesh* m = mf->mesh;
+    a                 = {};
+    a.elem_nodes      = m->elem_nodes.ptr;
+    a.elem_verts      = m->elem_verts.ptr;
+    a.dirichlet       = m->dirichlet.ptr;
+    a.tables          = mf->tables.ptr;
+    a.fields          = mf->fields;
+    a.ldf             = mf->ldf;
+    a.n_owned_dofs    = m->nOwnedDofs();
+    a.time            = mf->time;
+    a.dofs_per_node   = m->dofs_per_node;
+    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
+        a.field_inds[u] = mf->field_inds[u];
+    switch (which)
+    {
+    case 0:
+        a.elem_begin = 0;
+        a.elem_count = m->n_interior;
+        break;
+    case 1:
+        a.elem_begin = m->n_interior;
+        a.elem_count = m->n_elems - m->n_interior;
+        break;
+    case 2:
+        a.elem_begin = 0;
+        a.elem_count = m->n_elems;
+        break;
+    default:
+        setError("which must be 0 (interior), 1 (border) or 2 (all)");
+        return -1;
+    }
+    if (mf->kp.n_fields > 0 && !mf->fields)
+    {
+        setError("kernel reads %d external fields but l3k_mf_set_fields was not called", mf->kp.n_fields);
+        return -1;
+    }
+    if (ncols < 1 || ncols > mf->n_rhs)
+    {
+        // algsys/MatrixFreeSystem.hpp:1035-1037
+        setError("number of columns (%d) must be in [1, n_rhs = %d]", ncols, mf->n_rhs);
+        return -1;
+    }
+    return 0;
+}
+const l3k::dev::Instance* instanceFor(const l3k_mf* mf, int ncols)
+{
+    const auto* inst = l3k::dev::findInstance(mf->kernel_id, mf->mesh->order, mf->nq, ncols);
+    if (!inst)
+        setError("no device instantiation for kernel %d, order %d, nq %d, ncols %d: add it to L3K_FOR_EACH_INSTANCE "
+                 "(l3ster_amd/csrc/user_kernels.hpp) and rebuild",
+                 mf->kernel_id, mf->mesh->order, mf->nq, ncols);
+    return inst;
+}
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int l3k_version(void)
+{
+    return L3K_VERSION;
+}
+const char* l3k_last_error(void)
+{
+    return l3k::dev::lastError();
+}
+
+int l3k_gll_nodes(int n, double* x)
+{
+    if (n < 2 || !x)
+    {
+        setError("l3k_gll_nodes: need n >= 2");
+        return -1;
+    }
+    const auto v = l3k::host::gllNodes(n);
+    std::copy(v.begin(), v.end(), x);
+    return 0;
+}
+int l3k_gl_rule(int nq, double* x, double* w)
+{
+    if (nq < 1 || !x || !w)
+    {
+        setError("l3k_gl_rule: need nq >= 1");
+        return -1;
+    }
+    std::vector< double > xv, wv;
+    l3k::host::glRule(nq, xv, wv);
+    std::copy(xv.begin(), xv.end(), x);
+    std::copy(wv.begin(), wv.end(), w);
+    return 0;
+}
+int l3k_n_qps1d(int p, int value_order, int derivative_order)
+{
+    return value_order * p + derivative_order * (p - 1) + 1;
+}
+int l3k_basis_1d(int p, int nq, double* I, double* D)
+{
+    if (p < 1 || nq < 1 || !I || !D)
+    {
+        setError("l3k_basis_1d: bad arguments");
+        return -1;
+    }
+    std::vector< double > Iv, Dv;
+    l3k::host::basis1d(p, nq, Iv, Dv);
+    std::copy(Iv.begin(), Iv.end(), I);
+    std::copy(Dv.begin(), Dv.end(), D);
+    return 0;
+}
+int l3k_colloc_deriv(int nq, double* C)
+{
+    if (nq < 1 || !C)
+    {
+        setError("l3k_colloc_deriv: bad arguments");
+        return -1;
+    }
+    const auto v = l3k::host::collocDeriv(nq);
+    std::copy(v.begin(), v.end(), C);
+    return 0;
+}
+
+int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_t* param_bytes)
+{
+    const auto* k = findKernel(kernel_id);
+    if (!k)
+    {
+        setError("unknown kernel id %d", kernel_id);
+        return -1;
+    }
+    if (params)
+        *params = k->kp;
+    if (name)
+        *name = k->name;
+    if (param_bytes)
+        *param_bytes = k->bytes;
+    return 0;
+}
+int l3k_instance_count(void)
+{
+    return l3k::dev::instanceCount();
+}
+int l3k_instance_info(int i, int* kernel_id, int* order, int* nq, int* ncols)
+{
+    const auto* inst = l3k::dev::instanceAt(i);
+    if (!inst)
+    {
+        setError("instance index %d out of range", i);
+        return -1;
+    }
+    *kernel_id = inst->kernel_id;
+    *order     = inst->order;
+    *nq        = inst->nq;
+    *ncols     = inst->ncols;
+    return 0;
+}
+
+int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
+{
+    if (!out)
+    {
+        setError("l3k_ctx_create: out is null");
+        return -1;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+    {
+        setError("no HIP device available: libl3k has no CPU fallback (the device path is the product)");
+        return -2;
+    }
+    if (hip_device < 0 || hip_device >= count)
+    {
+        setError("hip_device %d outside [0,%d)", hip_device, count);
+        return -1;
+    }
+    L3K_HIP(hipSetDevice(hip_device));
+    *out = new l3k_ctx{hip_device, static_cast< hipStream_t >(hip_stream)};
+    return 0;
+}
+int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream)
+{
+    if (!ctx)
+    {
+        setError("null ctx");
+        return -1;
+    }
+    ctx->stream = static_cast< hipStream_t >(hip_stream);
+    return 0;
+}
+int l3k_ctx_synchronize(l3k_ctx* ctx)
+{
+    if (!ctx)
+    {
+        setError("null ctx");
+        return -1;
+    }
+    L3K_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int l3k_ctx_destroy(l3k_ctx* ctx)
+{
+    delete ctx;
+    return 0;
+}
+
+int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
+{
+    if (!ctx || !d || !out)
+    {
+        setError("l3k_mesh_create: null argument");
+        return -1;
+    }
+    if (d->dim != 3)
+    {
+        setError("device kernels exist for hex elements only (dim = 3); quads are covered by the CPU oracle");
+        return -1;
+    }
+    if (d->order < 1 || d->n_elems < 0 || d->n_interior_elems < 0 || d->n_interior_elems > d->n_elems ||
+        d->dofs_per_node < 1 || d->n_owned_nodes < 0 || d->n_ghost_nodes < 0 || !d->elem_nodes || !d->elem_verts)
+    {
+        setError("l3k_mesh_create: inconsistent descriptor");
+        return -1;
+    }
+    const int64_t N       = int64_t(d->order + 1) * (d->order + 1) * (d->order + 1);
+    const int64_t n_nodes = d->n_owned_nodes + d->n_ghost_nodes;
+    if (n_nodes * d->dofs_per_node >= (int64_t(1) << 31) * 8)
+    {
+        setError("too many local dofs");
+        return -1;
+    }
+    // operand shapes must match what the kernels assume: every node id inside [0, n_nodes)
+    for (int64_t i = 0; i < d->n_elems * N; ++i)
+        if (d->elem_nodes[i] >= static_cast< uint64_t >(n_nodes))
+        {
+            setError("elem_nodes[%lld] = %u is outside the local node range [0,%lld)", (long long)i, d->elem_nodes[i],
+                     (long long)n_nodes);
+            return -1;
+        }
+    L3K_HIP(hipSetDevice(ctx->device));
+    auto m           = std::make_unique< l3k_mesh >();
+    m->ctx           = ctx;
+    m->dim           = d->dim;
+    m->order         = d->order;
+    m->dofs_per_node = d->dofs_per_node;
+    m->n_elems       = d->n_elems;
+    m->n_interior    = d->n_interior_elems;
+    m->n_owned_nodes = d->n_owned_nodes;
+    m->n_ghost_nodes = d->n_ghost_nodes;
+    if (int rc = m->elem_nodes.upload(d->elem_nodes, size_t(d->n_elems * N), ctx->stream))
+        return rc;
+    if (int rc = m->elem_verts.upload(d->elem_verts, size_t(d->n_elems) * 24, ctx->stream))
+        return rc;
+    std::vector< int64_t > rows;
+    if (d->dirichlet)
+    {
+        if (int rc = m->dirichlet.upload(d->dirichlet, size_t(n_nodes * d->dofs_per_node), ctx->stream))
+            return rc;
+        for (int64_t i = 0; i < d->n_owned_nodes * d->dofs_per_node; ++i) // getOwnedDirichletDofs
+            if (d->dirichlet[i])
+                rows.push_back(i);
+        if (int rc = m->owned_dirichlet_rows.upload(rows.data(), rows.size(), ctx->stream))
+            return rc;
+    }
+    L3K_HIP(hipStreamSynchronize(ctx->stream)); // host arrays may be freed by the caller after return
+    *out = m.release();
+    return 0;
+}
+int l3k_mesh_destroy(l3k_mesh* mesh)
+{
+    delete mesh;
+    return 0;
+}
+
+int l3k_mf_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kparam_blob, size_t kparam_bytes,
+                  const l3k_asmopts* opts, const int* field_inds, int n_rhs, l3k_mf** out)
+{
+    if (!ctx || !mesh || !out)
+    {
+        setError("l3k_mf_create: null argument");
+        return -1;
+    }
+    const auto* k = findKernel(kernel_id);
+    if (!k)
+    {
+        setError("unknown kernel id %d", kernel_id);
+        return -1;
+    }
+    if (k->kp.dimension != mesh->dim)
+    {
+        setError("kernel dimension %d != mesh dimension %d", k->kp.dimension, mesh->dim);
+        return -1;
+    }
+    if (kparam_blob && kparam_bytes != k->bytes)
+    {
+        setError("kernel %s expects a %zu-byte parameter block, got %zu", k->name, k->bytes, kparam_bytes);
+        return -1;
+    }
+    if (n_rhs < 1)
+    {
+        setError("n_rhs must be >= 1");
+        return -1;
+    }
+    const l3k_asmopts o  = opts ? *opts : l3k_asmopts{1, 0, 0};
+    const int         nq = l3k_n_qps1d(mesh->order, o.value_order, o.derivative_order);
+    if (nq < mesh->order + 1)
+    {
+        setError("nq = %d < p+1 = %d: the collocation-derivative device algorithm needs nq >= p+1", nq, mesh->order + 1);
+        return -1;
+    }
+    auto mf       = std::make_unique< l3k_mf >();
+    mf->ctx       = ctx;
+    mf->mesh      = mesh;
+    mf->kernel_id = kernel_id;
+    mf->nq        = nq;
+    mf->n_rhs     = n_rhs;
+    mf->kp        = k->kp;
+    if (kparam_blob)
+        mf->blob.assign(static_cast< const char* >(kparam_blob), static_cast< const char* >(kparam_blob) + kparam_bytes);
+    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
+        mf->field_inds[u] = 0;
+    if (k->kp.n_unknowns > l3k::dev::max_unknowns)
+    {
+        setError("n_unknowns > %d unsupported", l3k::dev::max_unknowns);
+        return -1;
+    }
+    for (int u = 0; u < k->kp.n_unknowns; ++u)
+    {
+        const int fi = field_inds ? field_inds[u] : u;
+        if (fi < 0 || fi >= mesh->dofs_per_node)
+        {
+            setError("field_inds[%d] = %d outside [0, dofs_per_node = %d)", u, fi, mesh->dofs_per_node);
+            return -1;
+        }
+        mf->field_inds[u] = fi;
+    }
+    L3K_HIP(hipSetDevice(ctx->device));
+    const auto block = l3k::host::deviceTableBlock(mesh->order, nq);
+    if (int rc = mf->tables.upload(block.data(), block.size(), ctx->stream))
+        return rc;
+    L3K_HIP(hipStreamSynchronize(ctx->stream));
+    *out = mf.release();
+    return 0;
+}
+int l3k_mf_destroy(l3k_mf* mf)
+{
+    delete mf;
+    return 0;
+}
+int l3k_mf_set_fields(l3k_mf* mf, const double* d_soa, size_t ld)
+{
+    if (!mf)
+    {
+        setError("null mf");
+        return -1;
+    }
+    if (d_soa && ld < size_t(mf->mesh->n_owned_nodes + mf->mesh->n_ghost_nodes))
+    {
+        setError("field leading dimension %zu < number of local nodes", ld);
+        return -1;
+    }
+    mf->fields = d_soa;
+    mf->ldf    = ld;
+    return 0;
+}
+int l3k_mf_set_time(l3k_mf* mf, double time)
+{
+    if (!mf)
+    {
+        setError("null mf");
+        return -1;
+    }
+    mf->time = time;
+    return 0;
+}
+
+int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta)
+{
+    if (!mf || !d_y)
+    {
+        setError("l3k_mf_scale: null argument");
+        return -1;
+    }
+    const int64_t rows = mf->mesh->nOwnedDofs();
+    if (beta == 1. || rows == 0)
+        return 0;
+    hipLaunchKernelGGL(scaleKernel, dim3(gridFor(rows)), dim3(256), 0, mf->ctx->stream, d_y, ldy, rows, ncols, beta);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+
+int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg,
+                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha)
+{
+    if (!mf || !d_x || !d_y)
+    {
+        setError("l3k_mf_apply_elems: null argument");
+        return -1;
+    }
+    l3k::dev::ElemArgs a;
+    if (int rc = fillArgs(mf, which, ncols, a))
+        return rc;
+    const l3k_mesh* m = mf->mesh;
+    if (ldx < size_t(m->nOwnedDofs()) || ldy < size_t(m->nOwnedDofs()))
+    {
+        setError("leading dimension smaller than the number of owned dofs");
+        return -1;
+    }
+    if (m->n_ghost_nodes > 0 && which != 0 && (!d_xghost || !d_yghost))
+    {
+        setError("mesh has ghost nodes: border elements need the ghost import/export buffers");
+        return -1;
+    }
+    a.x     = d_x;
+    a.xg    = d_xghost;
+    a.y     = d_y;
+    a.yg    = d_yghost;
+    a.ldx   = ldx;
+    a.ldxg  = ldxg;
+    a.ldy   = ldy;
+    a.ldyg  = ldyg;
+    a.alpha = alpha;
+    const auto* inst = instanceFor(mf, ncols);
+    if (!inst)
+        return -4;
+    return inst->apply(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream);
+}
+
+int l3k_mf_dirichlet_rows(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha)
+{
+    if (!mf || !d_x || !d_y)
+    {
+        setError("l3k_mf_dirichlet_rows: null argument");
+        return -1;
+    }
+    const auto& rows = mf->mesh->owned_dirichlet_rows;
+    if (rows.n == 0)
+        return 0;
+    hipLaunchKernelGGL(dirichletRowsKernel, dim3(gridFor(int64_t(rows.n))), dim3(256), 0, mf->ctx->stream, rows.ptr,
+                       int64_t(rows.n), d_x, ldx, d_y, ldy, ncols, alpha);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+
+int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha, double beta)
+{
+    if (!mf)
+    {
+        setError("null mf");
+        return -1;
+    }
+    if (mf->mesh->n_ghost_nodes != 0)
+    {
+        setError("l3k_mf_apply is the single-rank form; this mesh has ghost nodes: use the split-phase entry points");
+        return -1;
+    }
+    if (int rc = l3k_mf_scale(mf, d_y, ldy, ncols, beta))
+        return rc;
+    if (int rc = l3k_mf_apply_elems(mf, 2, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha))
+        return rc;
+    return l3k_mf_dirichlet_rows(mf, d_x, ldx, d_y, ldy, ncols, alpha);
+}
+
+int l3k_pack_rows(l3k_ctx* ctx, const double* d_src, size_t ld, int ncols, const int32_t* d_idx, int64_t n, double* d_dst)
+{
+    if (!ctx || (n > 0 && (!d_src || !d_idx || !d_dst)))
+    {
+        setError("l3k_pack_rows: null argument");
+        return -1;
+    }
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(packKernel, dim3(gridFor(n)), dim3(256), 0, ctx->stream, d_src, ld, ncols, d_idx, n, d_dst);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_unpack_add_rows(l3k_ctx* ctx, const double* d_src, int64_t n, const int32_t* d_idx, double* d_dst, size_t ld,
+                        int ncols)
+{
+    if (!ctx || (n > 0 && (!d_src || !d_idx || !d_dst)))
+    {
+        setError("l3k_unpack_add_rows: null argument");
+        return -1;
+    }
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(unpackAddKernel, dim3(gridFor(n)), dim3(256), 0, ctx->stream, d_src, n, d_idx, d_dst, ld, ncols);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+
+int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
+                    size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg, int finalize)
+{
+    (void)d_diag_ghost;
+    if (!mf || !d_rhs)
+    {
+        setError("l3k_mf_diag_rhs: null argument");
+        return -1;
+    }
+    l3k::dev::ElemArgs a;
+    if (int rc = fillArgs(mf, which, mf->n_rhs, a))
+        return rc;
+    a.dirichlet_vals = d_dirichlet_vals;
+    a.ldg            = ldg;
+    a.y              = d_rhs;
+    a.ldy            = ldr;
+    a.yg             = d_rhs_ghost;
+    a.ldyg           = ldrg;
+    a.diag           = d_diag;
+    a.diag_g         = d_diag_ghost;
+    const auto* inst = instanceFor(mf, mf->n_rhs);
+    if (!inst)
+        return -4;
+    if (int rc = inst->diag_rhs(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream))
+        return rc;
+    if (finalize && mf->mesh->owned_dirichlet_rows.n > 0 && d_diag)
+    {
+        const auto& rows = mf->mesh->owned_dirichlet_rows;
+        hipLaunchKernelGGL(dirichletFinalizeKernel, dim3(gridFor(int64_t(rows.n))), dim3(256), 0, mf->ctx->stream, rows.ptr,
+                           int64_t(rows.n), d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, mf->n_rhs);
+        L3K_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum)
+{
+    (void)mf, (void)first, (void)count, (void)d_K, (void)d_F, (void)d_checksum;
+    setError("l3k_local_assemble: not built yet in this round");
+    return -5;
+}
+} // extern "C"

@@ -1,0 +1,79 @@
+// common.hpp -- shared declarations of the device layer (argument blocks, instance registry).
+#ifndef L3K_DEVICE_COMMON_HPP
+#define L3K_DEVICE_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "l3k/kernel_interface.hpp"
+
+namespace l3k::dev
+{
+inline constexpr int max_unknowns = 8;
+
+// 1-D tables of one (p, nq) pair in HBM, layout: I[n][nq] | C[nq][nq] | qw[nq] | qx[nq] | D[n][nq] | gll[n]
+struct TableLayout
+{
+    int n, nq;
+    constexpr int offI() const { return 0; }
+    constexpr int offC() const { return n * nq; }
+    constexpr int offW() const { return offC() + nq * nq; }
+    constexpr int offX() const { return offW() + nq; }
+    constexpr int offD() const { return offX() + nq; }
+    constexpr int offG() const { return offD() + n * nq; }
+    constexpr int size() const { return offG() + n; }
+};
+
+// Everything an element kernel needs; passed by value as the kernel argument (scalar loads).
+struct ElemArgs
+{
+    const uint32_t* elem_nodes; // [n_elems][N]
+    const double*   elem_verts; // [n_elems][8][3]
+    const uint8_t*  dirichlet;  // [n_local_dofs] or nullptr
+    const double*   tables;     // TableLayout
+    const double*   fields;     // SoA [F][ldf] or nullptr
+    size_t          ldf;
+    const double*   x;  // owned rows
+    const double*   xg; // ghost rows (or nullptr)
+    double*         y;
+    double*         yg;
+    size_t          ldx, ldxg, ldy, ldyg;
+    int64_t         n_owned_dofs;
+    int64_t         elem_begin, elem_count;
+    double          alpha, time;
+    int             dofs_per_node;
+    int             field_inds[max_unknowns];
+    // diag/rhs mode
+    const double* dirichlet_vals; // [n_local_dofs][R] (ld = ldg) or nullptr
+    size_t        ldg;
+    double*       diag;
+    double*       diag_g;
+    // local assembly
+    double* K;
+    double* F;
+    double* checksum;
+};
+
+using LaunchFn = int (*)(const ElemArgs&, const void* kparam_blob, hipStream_t stream);
+
+struct Instance
+{
+    int      kernel_id, order, nq, ncols;
+    LaunchFn apply;
+    LaunchFn diag_rhs;
+    LaunchFn assemble;
+};
+
+void            registerInstance(const Instance& inst);
+const Instance* findInstance(int kernel_id, int order, int nq, int ncols);
+int             instanceCount();
+const Instance* instanceAt(int i);
+
+template < typename K >
+struct KernelId;
+
+void setError(const char* fmt, ...);
+} // namespace l3k::dev
+#endif

@@ -1,0 +1,36 @@
+// instantiate.hpp -- included by the generated per-TU instance files (l3ster_amd/build.py writes them from
+// L3K_FOR_EACH_INSTANCE in user_kernels.hpp so that the heavy templates compile in parallel).
+#ifndef L3K_DEVICE_INSTANTIATE_HPP
+#define L3K_DEVICE_INSTANTIATE_HPP
+
+#include "../user_kernels.hpp"
+#include "sumfact_apply.hpp"
+
+namespace l3k::dev
+{
+#define L3K_X(id, T, name)                                                                                             \
+    template <>                                                                                                        \
+    struct KernelId< T >                                                                                               \
+    {                                                                                                                  \
+        static constexpr int value = id;                                                                               \
+    };
+L3K_FOR_EACH_KERNEL(L3K_X)
+#undef L3K_X
+} // namespace l3k::dev
+
+#define L3K_CAT2(a, b) a##b
+#define L3K_CAT(a, b) L3K_CAT2(a, b)
+#define L3K_INSTANTIATE(T, P, NQ, R)                                                                                   \
+    namespace                                                                                                          \
+    {                                                                                                                  \
+    const struct L3K_CAT(Registrar_, __LINE__)                                                                         \
+    {                                                                                                                  \
+        L3K_CAT(Registrar_, __LINE__)()                                                                                \
+        {                                                                                                              \
+            ::l3k::dev::registerInstance({::l3k::dev::KernelId< T >::value, P, NQ, R,                                  \
+                                          &::l3k::dev::launchSumfactApply< T, P, NQ, R, false >,                       \
+                                          &::l3k::dev::launchSumfactApply< T, P, NQ, R, true >, nullptr});            \
+        }                                                                                                              \
+    } L3K_CAT(registrar_, __LINE__);                                                                                   \
+    }
+#endif

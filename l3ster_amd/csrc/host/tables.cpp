@@ -1,0 +1,164 @@
+// tables.cpp -- see tables.hpp.  Well-conditioned generators (Newton on Legendre recurrences, barycentric Lagrange) in
+// long double; the reference's route (companion-matrix eigenvalues, monomial coefficients, Golub-Welsch:
+// math/Polynomial.hpp:98-122, math/LagrangeInterpolation.hpp:13-41, math/ComputeGaussRule.hpp:26-60) yields the same
+// numbers to ~1e-14 at p <= 6.
+#include "tables.hpp"
+
+#include <cmath>
+
+namespace l3k::host
+{
+namespace
+{
+using ld = long double;
+struct Leg
+{
+    ld P, dP;
+};
+Leg legendre(int n, ld x)
+{
+    if (n == 0)
+        return {1, 0};
+    ld pm = 1, pc = x;
+    for (int k = 2; k <= n; ++k)
+    {
+        const ld pn = ((2 * k - 1) * x * pc - (k - 1) * pm) / k;
+        pm          = pc;
+        pc          = pn;
+    }
+    return {pc, n * (x * pc - pm) / (x * x - 1)};
+}
+const ld pi_l = 3.14159265358979323846264338327950288L;
+} // namespace
+
+std::vector< double > gllNodes(int n)
+{
+    std::vector< double > x(n);
+    const int             N = n - 1;
+    x.front()               = -1.;
+    x.back()                = 1.;
+    for (int k = 1; k < N; ++k)
+    {
+        ld xk = -std::cos(pi_l * k / N);
+        for (int it = 0; it < 64; ++it)
+        {
+            const auto [P, dP] = legendre(N, xk);
+            const ld d2P       = (2 * xk * dP - ld(N) * (N + 1) * P) / (1 - xk * xk);
+            const ld step      = dP / d2P;
+            xk -= step;
+            if (std::fabs(step) < 1e-19L)
+                break;
+        }
+        x[k] = static_cast< double >(xk);
+    }
+    for (int k = 0; k < n / 2; ++k)
+    {
+        const double a = .5 * (x[n - 1 - k] - x[k]);
+        x[k]           = -a;
+        x[n - 1 - k]   = a;
+    }
+    if (n % 2)
+        x[n / 2] = 0.;
+    return x;
+}
+
+void glRule(int nq, std::vector< double >& x, std::vector< double >& w)
+{
+    x.assign(nq, 0.);
+    w.assign(nq, 0.);
+    for (int i = 0; i < nq; ++i)
+    {
+        ld xi = -std::cos(pi_l * (i + .75L) / (nq + .5L));
+        for (int it = 0; it < 64; ++it)
+        {
+            const auto [P, dP] = legendre(nq, xi);
+            const ld step      = P / dP;
+            xi -= step;
+            if (std::fabs(step) < 1e-19L)
+                break;
+        }
+        const auto [P, dP] = legendre(nq, xi);
+        x[i]               = static_cast< double >(xi);
+        w[i]               = static_cast< double >(2 / ((1 - xi * xi) * dP * dP));
+    }
+    if (nq % 2)
+        x[nq / 2] = 0.;
+}
+
+void lagrange(const std::vector< double >& nodes, double x, double* vals, double* ders)
+{
+    const int n = static_cast< int >(nodes.size());
+    for (int b = 0; b < n; ++b)
+    {
+        ld den = 1, val = 1, der = 0;
+        for (int j = 0; j < n; ++j)
+            if (j != b)
+            {
+                den *= ld(nodes[b]) - nodes[j];
+                val *= ld(x) - nodes[j];
+            }
+        for (int k = 0; k < n; ++k)
+        {
+            if (k == b)
+                continue;
+            ld pr = 1;
+            for (int j = 0; j < n; ++j)
+                if (j != b && j != k)
+                    pr *= ld(x) - nodes[j];
+            der += pr;
+        }
+        vals[b] = static_cast< double >(val / den);
+        if (ders)
+            ders[b] = static_cast< double >(der / den);
+    }
+}
+
+void basis1d(int p, int nq, std::vector< double >& I, std::vector< double >& D)
+{
+    const int             n   = p + 1;
+    const auto            gll = gllNodes(n);
+    std::vector< double > qx, qw, v(n), d(n);
+    glRule(nq, qx, qw);
+    I.assign(size_t(n) * nq, 0.);
+    D.assign(size_t(n) * nq, 0.);
+    for (int q = 0; q < nq; ++q)
+    {
+        lagrange(gll, qx[q], v.data(), d.data());
+        for (int b = 0; b < n; ++b)
+        {
+            I[b * nq + q] = v[b];
+            D[b * nq + q] = d[b];
+        }
+    }
+}
+
+std::vector< double > collocDeriv(int nq)
+{
+    std::vector< double > qx, qw, v(nq), d(nq), C(size_t(nq) * nq);
+    glRule(nq, qx, qw);
+    for (int q = 0; q < nq; ++q)
+    {
+        lagrange(qx, qx[q], v.data(), d.data());
+        for (int qp = 0; qp < nq; ++qp)
+            C[qp * nq + q] = d[qp];
+    }
+    return C;
+}
+
+std::vector< double > deviceTableBlock(int p, int nq)
+{
+    std::vector< double > I, D, qx, qw;
+    basis1d(p, nq, I, D);
+    glRule(nq, qx, qw);
+    const auto            C   = collocDeriv(nq);
+    const auto            gll = gllNodes(p + 1);
+    std::vector< double > out;
+    out.insert(out.end(), I.begin(), I.end());
+    out.insert(out.end(), C.begin(), C.end());
+    out.insert(out.end(), qw.begin(), qw.end());
+    out.insert(out.end(), qx.begin(), qx.end());
+    out.insert(out.end(), D.begin(), D.end());
+    out.insert(out.end(), gll.begin(), gll.end());
+    return out;
+}
+} // namespace l3k::host

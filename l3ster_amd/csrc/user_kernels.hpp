@@ -1,0 +1,150 @@
+// user_kernels.hpp -- the registered operator kernels (the "user code" of the reference, common/KernelInterface.hpp).
+//
+// Each kernel is a POD functor with the reference's (in, out) signature plus a `params` member and an optional
+// parameter block as data members.  To add a kernel: define the functor, add it to L3K_FOR_EACH_KERNEL with a fresh id
+// and list the (order, nq, ncols) shapes to instantiate in L3K_FOR_EACH_INSTANCE; rebuild (python -m l3ster_amd.build).
+#ifndef L3K_USER_KERNELS_HPP
+#define L3K_USER_KERNELS_HPP
+
+#include "l3k/kernel_interface.hpp"
+
+namespace l3k::kernels
+{
+// benchmarks/Diffusion3D.hpp:50-79 (== benchmarks/Kernels.hpp:85-113, tests/Kernels.hpp:55-81 with s = 0)
+struct Diffusion3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 7, .n_unknowns = 4};
+    double                        k = 1., s = 1.; // diffusivity, source
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In&, Out& out) const
+    {
+        auto& [operators, rhs] = out;
+        auto& [A0, Ax, Ay, Az] = operators;
+        // -k * div q = s
+        Ax(0, 1) = -k;
+        Ay(0, 2) = -k;
+        Az(0, 3) = -k;
+        rhs[0]   = s;
+        // grad T = q
+        A0(1, 1) = -1.;
+        Ax(1, 0) = 1.;
+        A0(2, 2) = -1.;
+        Ay(2, 0) = 1.;
+        A0(3, 3) = -1.;
+        Az(3, 0) = 1.;
+        // rot q = 0
+        Ay(4, 3) = 1.;
+        Az(4, 2) = -1.;
+        Ax(5, 3) = -1.;
+        Az(5, 1) = 1.;
+        Ax(6, 2) = 1.;
+        Ay(6, 1) = -1.;
+    }
+};
+
+// tests/Kernels.hpp:84-118: variable diffusivity passed as an external field
+struct Diffusion3DVar
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 7, .n_unknowns = 4, .n_fields = 1};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [field_vals, field_ders, _] = in;
+        const auto lambda                       = field_vals[0];
+        const auto& [dx, dy, dz]                = field_ders;
+        const auto dl_dx                        = dx[0];
+        const auto dl_dy                        = dy[0];
+        const auto dl_dz                        = dz[0];
+
+        auto& [operators, rhs] = out;
+        auto& [A0, Ax, Ay, Az] = operators;
+        // -grad k * q - k * div q = s
+        A0(0, 1) = -dl_dx;
+        A0(0, 2) = -dl_dy;
+        A0(0, 3) = -dl_dz;
+        Ax(0, 1) = -lambda;
+        Ay(0, 2) = -lambda;
+        Az(0, 3) = -lambda;
+        // grad T = q
+        A0(1, 1) = -1.;
+        Ax(1, 0) = 1.;
+        A0(2, 2) = -1.;
+        Ay(2, 0) = 1.;
+        A0(3, 3) = -1.;
+        Az(3, 0) = 1.;
+        // curl q = 0
+        Ay(4, 3) = 1.;
+        Az(4, 2) = -1.;
+        Ax(5, 3) = -1.;
+        Az(5, 1) = 1.;
+        Ax(6, 2) = 1.;
+        Ay(6, 1) = -1.;
+    }
+};
+
+// Config-5 synthetic: advection-diffusion-reaction in first-order form, unknowns (c, q),
+// velocity u = 3 interpolated fields (the karman-style "kernel reads interpolated field values"):
+//   sigma c + u . grad c - k div q = s,   grad c = q,   rot q = 0
+struct AdvDiff3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 7, .n_unknowns = 4, .n_fields = 3};
+    double                        k = 1., sigma = 1., s = 1.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [u, u_ders, point] = in;
+        auto& [operators, rhs]         = out;
+        auto& [A0, Ax, Ay, Az]         = operators;
+        A0(0, 0) = sigma;
+        Ax(0, 0) = u[0];
+        Ay(0, 0) = u[1];
+        Az(0, 0) = u[2];
+        Ax(0, 1) = -k;
+        Ay(0, 2) = -k;
+        Az(0, 3) = -k;
+        rhs[0]   = s;
+        A0(1, 1) = -1.;
+        Ax(1, 0) = 1.;
+        A0(2, 2) = -1.;
+        Ay(2, 0) = 1.;
+        A0(3, 3) = -1.;
+        Az(3, 0) = 1.;
+        Ay(4, 3) = 1.;
+        Az(4, 2) = -1.;
+        Ax(5, 3) = -1.;
+        Az(5, 1) = 1.;
+        Ax(6, 2) = 1.;
+        Ay(6, 1) = -1.;
+    }
+};
+} // namespace l3k::kernels
+
+// id, functor type, name
+#define L3K_FOR_EACH_KERNEL(X)                                                                                         \
+    X(0, ::l3k::kernels::Diffusion3D, "diffusion3d")                                                                   \
+    X(1, ::l3k::kernels::Diffusion3DVar, "diffusion3d_var")                                                            \
+    X(4, ::l3k::kernels::AdvDiff3D, "advdiff3d")
+
+// Shapes instantiated on the device: (functor, order p, quadrature points per direction nq, columns R).
+// nq = value_order*p + derivative_order*(p-1) + 1 (algsys/AssembleLocalSystem.hpp:32-35).
+#define L3K_FOR_EACH_INSTANCE(X)                                                                                       \
+    X(::l3k::kernels::Diffusion3D, 1, 2, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 2, 3, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 3, 4, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 4, 5, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 5, 6, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 6, 7, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 3, 7, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 3, 7, 3)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 2, 3, 2)                                                                            \
+    X(::l3k::kernels::Diffusion3DVar, 3, 7, 1)                                                                         \
+    X(::l3k::kernels::Diffusion3DVar, 3, 7, 2)                                                                         \
+    X(::l3k::kernels::Diffusion3DVar, 4, 5, 1)                                                                         \
+    X(::l3k::kernels::AdvDiff3D, 2, 3, 1)                                                                              \
+    X(::l3k::kernels::AdvDiff3D, 2, 3, 2)                                                                              \
+    X(::l3k::kernels::AdvDiff3D, 4, 5, 1)
+
+#endif

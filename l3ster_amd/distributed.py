@@ -1,0 +1,100 @@
+"""Multi-rank matrix-free operator: one process per GPU, ghost exchange by neighbour send/recv over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Replaces comm::Import / comm::Export (comm/ImportExport.hpp:130-215) and the schedule of
+MatrixFreeSystem::applyImpl (algsys/MatrixFreeSystem.hpp:1020-1140):
+
+    Y <- beta*Y, export buffer <- 0                      (:1038, :1048)
+    pack owned x rows shared with each upper neighbour, post import sends/receives     (:1055, ImportExport.hpp:295-372)
+    interior elements (owned dofs only) -- overlaps the import                         (:1073-1105)
+    wait for the import; border elements (read ghost x, add into the ghost export buffer)   (:1058-1072)
+    post export sends (ghost slabs are contiguous per owner) / receives                 (:1071, ImportExport.hpp:402-433)
+    unpack-add received contributions into owned rows                                   (:1107, ImportExport.hpp:448-470)
+    y[d] += alpha*x[d] on owned Dirichlet rows                                          (:1087-1098)
+
+The exchange is a neighbour all-to-all: one message per neighbour per direction, no collective on the apply path.
+`backend` supplies the local pieces (scale / pack_rows / apply_elems / unpack_add_rows / dirichlet_rows); in the product
+it is l3ster_amd.system.MatrixFreeSystem (HIP kernels through the C ABI).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HaloPlan:
+    """DOF-level exchange lists of one rank (ImportExportContext, comm/ImportExport.hpp:29-72)."""
+
+    def __init__(self, part, dofs_per_node, device):
+        dpn = dofs_per_node
+        self.n_ghost_dofs = part.n_ghost_nodes * dpn
+        self.sharers = []  # (rank, int32 device tensor of owned dof rows)  -- import send / export receive
+        self.owners = []   # (rank, ghost dof begin, ghost dof end)          -- import receive / export send
+        for i, nb in enumerate(part.nbr_rank):
+            nodes = part.send_nodes[i]
+            if len(nodes):
+                rows = (nodes.astype(np.int64)[:, None] * dpn + np.arange(dpn)[None, :]).reshape(-1)
+                self.sharers.append((nb, torch.as_tensor(rows.astype(np.int32), device=device)))
+            g0, g1 = part.ghost_ranges[i]
+            if g1 > g0:
+                self.owners.append((nb, g0 * dpn, g1 * dpn))
+
+
+class DistributedOperator:
+    def __init__(self, backend, plan, group=None):
+        self.backend, self.plan, self.group = backend, plan, group
+        self._bufs = {}
+
+    def _buffers(self, ncols, like):
+        key = (ncols, like.device)
+        if key not in self._bufs:
+            mk = lambda n: torch.zeros((ncols, max(n, 1)), dtype=torch.float64, device=like.device)
+            self._bufs[key] = dict(
+                xg=mk(self.plan.n_ghost_dofs), yg=mk(self.plan.n_ghost_dofs),
+                send=[mk(idx.numel()) for _, idx in self.plan.sharers],
+                recv=[mk(idx.numel()) for _, idx in self.plan.sharers],
+                stage=[mk(e - b) for _, b, e in self.plan.owners])
+        return self._bufs[key]
+
+    def apply(self, X, Y, alpha=1.0, beta=0.0):
+        be, plan = self.backend, self.plan
+        nc = X.shape[0]
+        b = self._buffers(nc, X)
+        xg, yg = b["xg"], b["yg"]
+        be.scale(Y, beta)
+        yg.zero_()
+        # ---- import: owner -> sharer
+        ops = []
+        for (nb, idx), sbuf in zip(plan.sharers, b["send"]):
+            be.pack_rows(X, idx, sbuf)
+            ops.append(dist.P2POp(dist.isend, sbuf, nb, self.group))
+        recv_targets = []
+        for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
+            tgt = xg[:, g0:g1] if nc == 1 else stage  # one column: receive straight into the ghost slab
+            recv_targets.append(tgt)
+            ops.append(dist.P2POp(dist.irecv, tgt, nb, self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        be.apply_elems(0, X, None, Y, None, alpha)  # interior: overlaps the exchange
+        for r in reqs:
+            r.wait()
+        if nc > 1:
+            for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
+                xg[:, g0:g1].copy_(stage)
+        # ---- border elements, then export: sharer -> owner
+        be.apply_elems(1, X, xg, Y, yg, alpha)
+        ops = []
+        for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
+            if nc == 1:
+                src = yg[:, g0:g1]
+            else:
+                stage.copy_(yg[:, g0:g1])
+                src = stage
+            ops.append(dist.P2POp(dist.isend, src, nb, self.group))
+        for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
+            ops.append(dist.P2POp(dist.irecv, rbuf, nb, self.group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        for r in reqs:
+            r.wait()
+        for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
+            be.unpack_add_rows(rbuf, idx, Y)
+        be.dirichlet_rows(X, Y, alpha)
+        return Y

@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI (include/l3k.h).
+
+Mirrors (names, argument meaning, error behaviour) for this path only:
+  * tables            -- math::getLobattoRuleAbsc, quad::getReferenceQuadrature, SumFactorization tables
+  * CubePartition     -- generateAndDistributeMesh for structured cubes (comm/DistributeMesh.hpp:284-299)
+  * MatrixFreeSystem  -- algsys::MatrixFreeSystem: assembleProblem -> Operator.apply(X, Y, alpha, beta)
+                         (algsys/MatrixFreeSystem.hpp:24-89,1020-1140)
+Vectors are torch tensors of shape (ncols, n_owned_dofs), i.e. column-major [row][col] multivectors with owned rows
+only -- the host-view layout of the Tpetra multivectors of the reference.  torch is plumbing here (device memory,
+streams); all compute goes through libl3k.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import L3KError, check
+
+KERNEL_DIFFUSION3D = 0
+KERNEL_DIFFUSION3D_VAR = 1
+KERNEL_ADVDIFF3D = 4
+
+
+# ------------------------------------------------------------------------------------------------------- tables
+def gll_nodes(n):
+    x = np.zeros(n)
+    check(capi.load().l3k_gll_nodes(n, x.ctypes.data_as(capi.c_double_p)))
+    return x
+
+
+def gl_rule(nq):
+    x, w = np.zeros(nq), np.zeros(nq)
+    check(capi.load().l3k_gl_rule(nq, x.ctypes.data_as(capi.c_double_p), w.ctypes.data_as(capi.c_double_p)))
+    return x, w
+
+
+def n_qps1d(p, value_order=1, derivative_order=0):
+    return capi.load().l3k_n_qps1d(p, value_order, derivative_order)
+
+
+def basis_1d(p, nq):
+    I, D = np.zeros((p + 1, nq)), np.zeros((p + 1, nq))
+    check(capi.load().l3k_basis_1d(p, nq, I.ctypes.data_as(capi.c_double_p), D.ctypes.data_as(capi.c_double_p)))
+    return I, D
+
+
+def colloc_deriv(nq):
+    Cm = np.zeros((nq, nq))
+    check(capi.load().l3k_colloc_deriv(nq, Cm.ctypes.data_as(capi.c_double_p)))
+    return Cm
+
+
+def kernel_info(kernel_id):
+    kp, name, nbytes = capi.KParams(), C.c_char_p(), C.c_size_t()
+    check(capi.load().l3k_kernel_info(kernel_id, C.byref(kp), C.byref(name), C.byref(nbytes)))
+    return dict(dimension=kp.dimension, n_equations=kp.n_equations, n_unknowns=kp.n_unknowns, n_fields=kp.n_fields,
+                name=name.value.decode(), param_bytes=nbytes.value)
+
+
+def instances():
+    lib = capi.load()
+    out = []
+    for i in range(lib.l3k_instance_count()):
+        v = [C.c_int() for _ in range(4)]
+        check(lib.l3k_instance_info(i, *[C.byref(x) for x in v]))
+        out.append(tuple(x.value for x in v))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------- mesh
+class CubePartition:
+    """One rank's block of a structured order-p hex mesh of [0,1]^3 (host arrays, reference numbering conventions)."""
+
+    def __init__(self, ne, order, parts=(1, 1, 1), rank=0, perturb=0.0):
+        lib = capi.load()
+        ne = (ne,) * 3 if np.isscalar(ne) else tuple(ne)
+        self.ne, self.order, self.parts, self.rank = ne, order, tuple(parts), rank
+        h = C.c_void_p()
+        check(lib.l3k_cube_partition_create((C.c_int * 3)(*ne), order, (C.c_int * 3)(*parts), rank, perturb,
+                                            C.byref(h)))
+        try:
+            v = capi.HostMeshView()
+            check(lib.l3k_hostmesh_view_get(h, C.byref(v)))
+            N = (order + 1) ** 3
+            as_np = lambda ptr, shape: np.ctypeslib.as_array(ptr, shape=shape).copy() if np.prod(shape) else \
+                np.zeros(shape, dtype=np.ctypeslib.as_ctypes_type(ptr._type_))
+            self.dim = 3
+            self.n_elems, self.n_interior_elems = v.n_elems, v.n_interior_elems
+            self.n_owned_nodes, self.n_ghost_nodes = v.n_owned_nodes, v.n_ghost_nodes
+            self.global_node_base, self.n_global_nodes = v.global_node_base, v.n_global_nodes
+            self.elem_nodes = as_np(v.elem_nodes, (v.n_elems, N))
+            self.elem_verts = as_np(v.elem_verts, (v.n_elems, 8, 3))
+            nl = v.n_owned_nodes + v.n_ghost_nodes
+            self.node_grid_id = as_np(v.node_grid_id, (nl,))
+            self.node_boundary = as_np(v.node_boundary, (nl,))
+            nn = v.n_nbrs
+            self.nbr_rank = [v.nbr_rank[i] for i in range(nn)]
+            so = [v.send_offsets[i] for i in range(nn + 1)]
+            go = [v.ghost_offsets[i] for i in range(nn + 1)]
+            send = as_np(v.send_nodes, (so[-1],)) if so[-1] else np.zeros(0, np.int32)
+            self.send_nodes = [send[so[i]:so[i + 1]] for i in range(nn)]
+            self.ghost_ranges = [(go[i], go[i + 1]) for i in range(nn)]
+        finally:
+            lib.l3k_hostmesh_destroy(h)
+
+    @property
+    def n_local_nodes(self):
+        return self.n_owned_nodes + self.n_ghost_nodes
+
+    def dirichlet_mask(self, dofs_per_node, unknowns=(0,), sides=range(6)):
+        """Byte mask over local dofs: the listed unknowns on the listed cube sides (BCDefinition::defineDirichlet,
+        benchmarks/Diffusion3D.hpp:39-41)."""
+        side_bits = 0
+        for s in sides:
+            side_bits |= 1 << s
+        on = (self.node_boundary & side_bits) != 0
+        mask = np.zeros((self.n_local_nodes, dofs_per_node), dtype=np.uint8)
+        for u in unknowns:
+            mask[on, u] = 1
+        return mask.reshape(-1)
+
+    def synthetic_vector(self, dofs_per_node, seed=42, ncols=1):
+        """x ~ U(-1,1) as a function of (partition-independent grid node id, dof, column): every partition of the same
+        mesh sees the same global vector.  Counter-based splitmix64.  Shape (ncols, n_local_dofs)."""
+        key = (self.node_grid_id.astype(np.uint64)[:, None] * np.uint64(dofs_per_node) +
+               np.arange(dofs_per_node, dtype=np.uint64)[None, :]).reshape(-1)
+        out = np.empty((ncols, key.size))
+        for c in range(ncols):
+            with np.errstate(over="ignore"):
+                z = key + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(c) * np.uint64(0xD1B54A32D192ED03)
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                z = z ^ (z >> np.uint64(31))
+            out[c] = (z >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
+        return out
+
+
+def synthetic_vector_torch(node_grid_id, dofs_per_node, device, seed=42, ncols=1):
+    """Same function as CubePartition.synthetic_vector, evaluated with torch on `device` (int64 two's-complement
+    arithmetic == uint64 arithmetic modulo 2^64; logical shifts emulated by masking)."""
+    import torch
+
+    def s64(v):  # python int -> signed 64-bit representative
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    ids = torch.as_tensor(node_grid_id, dtype=torch.int64, device=device)
+    key = (ids[:, None] * dofs_per_node + torch.arange(dofs_per_node, dtype=torch.int64, device=device)[None, :]).reshape(-1)
+    out = torch.empty((ncols, key.numel()), dtype=torch.float64, device=device)
+    for c in range(ncols):
+        z = key + s64(seed * 0x9E3779B97F4A7C15 + c * 0xD1B54A32D192ED03)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        out[c] = lsr(z, 11).to(torch.float64) * (2.0 / (1 << 53)) - 1.0
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------- device
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        check(capi.load().l3k_ctx_create(device, C.c_void_p(stream or 0), C.byref(self._h)))
+        self.device = device
+
+    def set_stream(self, stream):
+        check(capi.load().l3k_ctx_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        check(capi.load().l3k_ctx_synchronize(self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.load().l3k_ctx_destroy(self._h)
+            self._h = None
+
+
+class DeviceMesh:
+    def __init__(self, ctx, part, dofs_per_node, dirichlet=None):
+        self.ctx, self.part, self.dofs_per_node = ctx, part, dofs_per_node
+        d = capi.MeshDesc()
+        d.dim, d.order = part.dim, part.order
+        d.n_elems, d.n_interior_elems = part.n_elems, part.n_interior_elems
+        en = np.ascontiguousarray(part.elem_nodes, dtype=np.uint32)
+        ev = np.ascontiguousarray(part.elem_verts, dtype=np.float64)
+        d.elem_nodes = en.ctypes.data_as(capi.c_uint32_p)
+        d.elem_verts = ev.ctypes.data_as(capi.c_double_p)
+        d.n_owned_nodes, d.n_ghost_nodes = part.n_owned_nodes, part.n_ghost_nodes
+        d.dofs_per_node = dofs_per_node
+        if dirichlet is not None:
+            dm = np.ascontiguousarray(dirichlet, dtype=np.uint8)
+            if dm.size != part.n_local_nodes * dofs_per_node:
+                raise L3KError("dirichlet mask must cover every local dof")
+            d.dirichlet = dm.ctypes.data_as(capi.c_uint8_p)
+        self._h = C.c_void_p()
+        check(capi.load().l3k_mesh_create(ctx._h, C.byref(d), C.byref(self._h)))
+        self.n_owned_dofs = part.n_owned_nodes * dofs_per_node
+        self.n_ghost_dofs = part.n_ghost_nodes * dofs_per_node
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.load().l3k_mesh_destroy(self._h)
+            self._h = None
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class MatrixFreeSystem:
+    """algsys::MatrixFreeSystem for one rank: kernel + mesh -> operator.  apply() is Operator::apply
+    (Y <- alpha*A*X + beta*Y, algsys/MatrixFreeSystem.hpp:34-41,1038)."""
+
+    def __init__(self, mesh, kernel_id, kernel_params=None, asm_opts=(1, 0, 0), field_inds=None, n_rhs=1):
+        self.mesh, self.ctx, self.kernel_id, self.n_rhs = mesh, mesh.ctx, kernel_id, n_rhs
+        self.info = kernel_info(kernel_id)
+        blob = None
+        nbytes = 0
+        if kernel_params is not None:
+            arr = np.ascontiguousarray(kernel_params, dtype=np.float64)
+            blob, nbytes = arr.ctypes.data_as(C.c_void_p), arr.nbytes
+        opts = capi.AsmOpts(*asm_opts)
+        fi = None
+        if field_inds is not None:
+            fi = (C.c_int * len(field_inds))(*field_inds)
+        self._h = C.c_void_p()
+        check(capi.load().l3k_mf_create(self.ctx._h, mesh._h, kernel_id, blob, nbytes, C.byref(opts), fi, n_rhs,
+                                        C.byref(self._h)))
+        self._fields = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            capi.load().l3k_mf_destroy(self._h)
+            self._h = None
+
+    # post::FieldAccess: SoA (n_fields, n_local_nodes) device tensor, kept alive here
+    def set_fields(self, fields):
+        if fields is not None and (fields.dim() != 2 or not fields.is_contiguous()):
+            raise L3KError("fields must be a contiguous (n_fields, n_local_nodes) tensor")
+        self._fields = fields
+        check(capi.load().l3k_mf_set_fields(self._h, _ptr(fields), 0 if fields is None else fields.shape[1]))
+
+    def set_time(self, t):
+        check(capi.load().l3k_mf_set_time(self._h, float(t)))
+
+    @staticmethod
+    def _cols(t):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise L3KError("multivectors are (ncols, ld) tensors with unit stride along rows")
+        return t.shape[0], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+    def apply(self, X, Y, alpha=1.0, beta=0.0):
+        nc, ldx = self._cols(X)
+        nc2, ldy = self._cols(Y)
+        if nc != nc2:
+            raise L3KError("X and Y must have the same number of columns")  # MatrixFreeSystem.hpp:1035
+        check(capi.load().l3k_mf_apply(self._h, _ptr(X), ldx, _ptr(Y), ldy, nc, alpha, beta))
+        return Y
+
+    # split-phase pieces (used by DistributedOperator)
+    def scale(self, Y, beta):
+        nc, ldy = self._cols(Y)
+        check(capi.load().l3k_mf_scale(self._h, _ptr(Y), ldy, nc, beta))
+
+    def apply_elems(self, which, X, XG, Y, YG, alpha):
+        nc, ldx = self._cols(X)
+        _, ldy = self._cols(Y)
+        ldxg = XG.shape[1] if XG is not None else 0
+        ldyg = YG.shape[1] if YG is not None else 0
+        check(capi.load().l3k_mf_apply_elems(self._h, which, _ptr(X), ldx, _ptr(XG), ldxg, _ptr(Y), ldy, _ptr(YG), ldyg,
+                                             nc, alpha))
+
+    def dirichlet_rows(self, X, Y, alpha):
+        nc, ldx = self._cols(X)
+        _, ldy = self._cols(Y)
+        check(capi.load().l3k_mf_dirichlet_rows(self._h, _ptr(X), ldx, _ptr(Y), ldy, nc, alpha))
+
+    def pack_rows(self, src, idx, dst):
+        nc, ld = self._cols(src)
+        check(capi.load().l3k_pack_rows(self.ctx._h, _ptr(src), ld, nc, _ptr(idx), idx.numel(), _ptr(dst)))
+
+    def unpack_add_rows(self, src, idx, dst):
+        nc, ld = self._cols(dst)
+        check(capi.load().l3k_unpack_add_rows(self.ctx._h, _ptr(src), idx.numel(), _ptr(idx), _ptr(dst), ld, nc))
+
+    def new_ghost_buffer(self, ncols, like):
+        import torch
+        return torch.zeros((ncols, max(self.mesh.n_ghost_dofs, 1)), dtype=torch.float64, device=like.device)

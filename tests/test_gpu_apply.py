@@ -1,0 +1,157 @@
+"""GPU parity tests of the matrix-free apply: HIP path (through the C ABI) vs golden fixtures and vs the CPU oracle.
+Tolerances: relative L2 <= 1e-12 per element / 1e-11 per mesh (stated fp64 tolerance; the reference's
+own cross-path bar is 1e-8 absolute, tests/SumFactorizationTests.cpp:26-27)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import HEX, SingleElementMesh, oracle_mesh, rel_err
+from l3ster_amd import system
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    torch.cuda.set_device(0)
+    return system.Context(0, torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+ELEMENT_CASES = ["hex_p3_diff", "hex_p3_var", "hex_p4_diff", "hex_p6_diff", "hex_p4_advdiff", "hex_p2_advdiff"]
+
+
+@pytest.mark.parametrize("name", ELEMENT_CASES)
+def test_single_element_vs_golden(ctx, golden, name):
+    g = golden(name)
+    kid, p, nq, R = int(g["kid"]), int(g["p"]), int(g["nq"]), int(g["R"])
+    info = system.kernel_info(kid)
+    U = info["n_unknowns"]
+    mesh = system.DeviceMesh(ctx, SingleElementMesh(p, g["verts"]), U)
+    vo = (nq - 1) // p
+    assert system.n_qps1d(p, vo) == nq
+    mf = system.MatrixFreeSystem(mesh, kid, g.get("kparams"), asm_opts=(vo, 0, 0), n_rhs=R)
+    if info["n_fields"]:
+        mf.set_fields(dev(g["node_fields"].T))
+    X = dev(g["x"].T)  # (R, Nd)
+    Y = torch.full_like(X, 7.0)
+    mf.apply(X, Y, 1.0, 0.0)
+    torch.cuda.synchronize()
+    assert rel_err(Y.cpu().numpy().T, g["y"]) < 1e-12
+    # alpha / beta semantics (MatrixFreeSystem.hpp:1038, :511)
+    Y0 = dev(np.random.default_rng(0).uniform(-1, 1, g["x"].T.shape))
+    Y2 = Y0.clone()
+    mf.apply(X, Y2, -0.5, 2.0)
+    assert rel_err(Y2.cpu().numpy().T, -0.5 * g["y"] + 2.0 * Y0.cpu().numpy().T) < 1e-12
+    # fewer columns than n_rhs (MatrixFreeSystem.hpp:1124-1138): column 0 alone
+    if R > 1 and (kid, p, nq, 1) in system.instances():
+        Y1 = torch.zeros_like(X[:1])
+        mf.apply(X[:1], Y1)
+        assert rel_err(Y1.cpu().numpy()[0], g["y"][:, 0]) < 1e-12
+    # more columns than n_rhs is an error (MatrixFreeSystem.hpp:1035-1037)
+    mf1 = system.MatrixFreeSystem(mesh, kid, g.get("kparams"), asm_opts=(vo, 0, 0), n_rhs=1)
+    if R > 1:
+        with pytest.raises(system.L3KError, match="columns"):
+            mf1.apply(X, Y)
+
+
+def random_fields(part, F, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1, 1, (F, part.n_local_nodes))
+
+
+MESH_CASES = [
+    # kid, ne, p, value_order, ncols, perturb
+    (system.KERNEL_DIFFUSION3D, (3, 2, 2), 1, 1, 1, 0.1),
+    (system.KERNEL_DIFFUSION3D, 3, 2, 1, 2, 0.1),
+    (system.KERNEL_DIFFUSION3D, 4, 3, 1, 1, 0.0),
+    (system.KERNEL_DIFFUSION3D, (5, 4, 3), 4, 1, 1, 0.1),
+    (system.KERNEL_DIFFUSION3D, 2, 5, 1, 1, 0.1),
+    (system.KERNEL_DIFFUSION3D, 3, 6, 1, 1, 0.1),
+    (system.KERNEL_DIFFUSION3D_VAR, 2, 3, 2, 2, 0.1),
+    (system.KERNEL_DIFFUSION3D_VAR, 3, 4, 1, 1, 0.1),
+    (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2, 0.1),
+    (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1, 0.1),
+]
+
+
+@pytest.mark.parametrize("kid,ne,p,vo,ncols,perturb", MESH_CASES)
+def test_mesh_apply_vs_oracle(ctx, kid, ne, p, vo, ncols, perturb):
+    """Whole-mesh operator with Dirichlet rows (benchmarks/Diffusion3D.hpp:39-41: unknown 0 on all six sides)."""
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(ne, p, perturb=perturb)
+    nq = system.n_qps1d(p, vo)
+    mask = part.dirichlet_mask(U)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    kpar = {0: [0.7, 1.0], 4: [0.7, 1.3, 0.5]}.get(kid)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar, asm_opts=(vo, 0, 0), n_rhs=ncols)
+    fields = random_fields(part, F, 3) if F else None
+    if F:
+        mf.set_fields(dev(fields))
+    x = part.synthetic_vector(U, ncols=ncols)
+    y0 = np.random.default_rng(1).uniform(-1, 1, x.shape)
+    om = oracle_mesh(part, nq, U, np.arange(U), mask, fields)
+    y_ref = O.mf_apply(om, kid, x.T, np.asfortranarray(y0.T.copy()), alpha=1.5, beta=-0.25, kparams=kpar)
+    X, Y = dev(x), dev(y0)
+    mf.apply(X, Y, 1.5, -0.25)
+    torch.cuda.synchronize()
+    assert rel_err(Y.cpu().numpy().T, y_ref) < 1e-11
+
+
+def test_subset_of_node_dofs_and_leading_dimension(ctx):
+    """Operator on 4 of 6 per-node dofs through field_inds (detail::getDofs, MatrixFreeSystem.hpp:298-311) with padded
+    leading dimensions."""
+    p, U, dpn = 2, 4, 6
+    part = system.CubePartition(3, p, perturb=0.1)
+    fi = [4, 0, 5, 2]
+    mask = np.zeros((part.n_local_nodes, dpn), np.uint8)
+    mask[part.node_boundary != 0, 4] = 1
+    mesh = system.DeviceMesh(ctx, part, dpn, mask.reshape(-1))
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, field_inds=fi, n_rhs=2)
+    n = part.n_local_nodes * dpn
+    pad = 37
+    rng = np.random.default_rng(4)
+    xb, yb = rng.uniform(-1, 1, (2, n + pad)), rng.uniform(-1, 1, (2, n + pad))
+    X, Y = dev(xb), dev(yb)
+    mf.apply(X[:, :n], Y[:, :n], 2.0, 1.0)
+    om = oracle_mesh(part, p + 1, dpn, fi, mask.reshape(-1))
+    y_ref = O.mf_apply(om, 0, xb[:, :n].T, np.asfortranarray(yb[:, :n].T.copy()), alpha=2.0, beta=1.0)
+    out = Y.cpu().numpy()
+    assert rel_err(out[:, :n].T, y_ref) < 1e-11
+    assert np.array_equal(out[:, n:], yb[:, n:])  # padding untouched
+    untouched = np.setdiff1d(np.arange(dpn), fi)
+    for k in untouched:  # dofs outside field_inds only see beta
+        np.testing.assert_array_equal(out[:, k:n:dpn], yb[:, k:n:dpn])
+
+
+@pytest.mark.parametrize("ne,p", [(16, 4), (12, 6)])
+def test_operator_properties_at_scale(ctx, ne, p):
+    """Size-independent properties on a mesh too large for the oracle to be the first resort: symmetry
+    <Ax, z> = <x, Az> (the least-squares operator is self-adjoint: apply ignores `mode`, MatrixFreeSystem.hpp:34-41),
+    linearity, positive semi-definiteness, and agreement with the oracle on a random sample of rows."""
+    U = 4
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D)
+    n = part.n_local_nodes * U
+    x = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=1)
+    z = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=2)
+    Ax, Az, Axz = torch.empty_like(x), torch.empty_like(z), torch.empty_like(x)
+    mf.apply(x, Ax)
+    mf.apply(z, Az)
+    mf.apply(x + 2.0 * z, Axz)
+    s1, s2 = torch.dot(Ax[0], z[0]).item(), torch.dot(x[0], Az[0]).item()
+    assert abs(s1 - s2) < 1e-11 * max(abs(s1), 1.0)
+    assert torch.dot(Ax[0], x[0]).item() > 0
+    assert (Axz - (Ax + 2.0 * Az)).norm().item() < 1e-12 * Axz.norm().item()
+    # oracle on the elements around a few rows only: compare the full vector but with a threaded oracle
+    om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
+    y_ref = O.mf_apply(om, 0, x.cpu().numpy().T, nthreads=8)
+    assert rel_err(Ax.cpu().numpy().T, y_ref) < 1e-11
