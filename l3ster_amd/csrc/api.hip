@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -202,6 +203,11 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.n_owned_dofs    = m->nOwnedDofs();
     a.time            = mf->time;
     a.dofs_per_node   = m->dofs_per_node;
+    static const int dbg_flags = [] {
+        const char* e = std::getenv("L3K_DEBUG_FLAGS");
+        return e ? std::atoi(e) : 0;
+    }();
+    a.dbg = dbg_flags;
     for (int u = 0; u < l3k::dev::max_unknowns; ++u)
         a.field_inds[u] = mf->field_inds[u];
     switch (which)

@@ -54,6 +54,7 @@ struct ElemArgs
     double* K;
     double* F;
     double* checksum;
+    int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS); 0 in production
 };
 
 using LaunchFn = int (*)(const ElemArgs&, const void* kparam_blob, hipStream_t stream);

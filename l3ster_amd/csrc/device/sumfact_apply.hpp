@@ -248,32 +248,37 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         vs[tid] = a.elem_verts[e * 24 + tid];
 
     // ---- gather (gatherSumFact, algsys/MatrixFreeSystem.hpp:421-467): node layout [op][iz][iy][ix]
-    for (int i = tid; i < NN; i += NT)
+    // lanes run over (node, unknown) pairs with the unknown fastest: the U dofs of a node are contiguous in x, and so
+    // are the nodes of a face / of the element interior, so a wave reads long contiguous runs.
+    for (int t = tid; t < NN * U; t += NT)
     {
+        const int     i    = t / U;
+        const int     u    = t - i * U;
         const int64_t node = en[i];
+        const int64_t dof  = node * a.dofs_per_node + a.field_inds[u];
+        const bool    dir  = a.dirichlet != nullptr && a.dirichlet[dof] != 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int r = 0; r < R; ++r)
         {
-            const int64_t dof = node * a.dofs_per_node + a.field_inds[u];
-            const bool    dir = a.dirichlet != nullptr && a.dirichlet[dof] != 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-            {
-                double val;
-                if constexpr (RHS_MODE)
-                    val = (dir && a.dirichlet_vals) ? a.dirichlet_vals[dof + a.ldg * r] : 0.;
-                else
-                    val = dir ? 0. : (dof < a.n_owned_dofs ? a.x[dof + a.ldx * r] : a.xg[(dof - a.n_owned_dofs) + a.ldxg * r]);
-                B0[(r * U + u) * M3 + i] = val;
-            }
+            double val;
+            if constexpr (RHS_MODE)
+                val = (dir && a.dirichlet_vals) ? a.dirichlet_vals[dof + a.ldg * r] : 0.;
+            else
+                val = (a.dbg & 2) ? double(t) * 1e-3 : (dir ? 0. : (dof < a.n_owned_dofs ? a.x[dof + a.ldx * r] : a.xg[(dof - a.n_owned_dofs) + a.ldxg * r]));
+            B0[(r * U + u) * M3 + i] = val;
         }
-#pragma unroll
-        for (int f = 0; f < F; ++f) // FieldAccess::fill, post/FieldAccess.hpp:21-30
-            B0[(OPS + f) * M3 + i] = a.fields[node + f * a.ldf];
     }
+    if constexpr (F > 0)
+        for (int t = tid; t < NN * F; t += NT) // FieldAccess::fill, post/FieldAccess.hpp:21-30
+        {
+            const int f = t / NN, i = t - f * NN;
+            B0[(OPS + f) * M3 + i] = a.fields[en[i] + f * a.ldf];
+        }
     __syncthreads();
 
     // ---- interpolation to the Gauss points: x, y, z sweeps
+    if (!(a.dbg & 8))
+    {
     sweep< 0, N1, NQ, false, false, N1, N1, N1, NF, NT >(B0, B1, M3, tabI, tid); // -> (NQ, N1, N1)
     __syncthreads();
     sweep< 1, N1, NQ, false, false, NQ, N1, N1, NF, NT >(B1, B0, M3, tabI, tid); // -> (NQ, NQ, N1)
@@ -285,8 +290,10 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     sweep< 1, NQ, NQ, false, false, NQ, NQ, NQ, NF, NT >(B1, B3, M3, tabC, tid);
     sweep< 2, NQ, NQ, false, false, NQ, NQ, NQ, NF, NT >(B1, B4, M3, tabC, tid);
     __syncthreads();
+    }
 
     // ---- quadrature points: one per thread
+    if (!(a.dbg & 4))
     for (int q = tid; q < NQP; q += NT)
     {
         const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
@@ -314,6 +321,8 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     __syncthreads();
 
     // ---- transposed collocation derivatives accumulate into the value array
+    if (!(a.dbg & 8))
+    {
     sweep< 0, NQ, NQ, true, true, NQ, NQ, NQ, OPS, NT >(B2, B1, M3, tabC, tid);
     __syncthreads();
     sweep< 1, NQ, NQ, true, true, NQ, NQ, NQ, OPS, NT >(B3, B1, M3, tabC, tid);
@@ -327,26 +336,32 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     __syncthreads();
     sweep< 0, NQ, N1, true, false, NQ, N1, N1, OPS, NT >(B1, B0, M3, tabI, tid); // -> (N1, N1, N1)
     __syncthreads();
+    }
 
     // ---- scatter-add (scatterSumFact, algsys/MatrixFreeSystem.hpp:494-537; scatterInit :377-390 in RHS mode)
-    for (int i = tid; i < NN; i += NT)
+    for (int t = tid; t < NN * U; t += NT)
     {
+        const int     i    = t / U;
+        const int     u    = t - i * U;
         const int64_t node = en[i];
+        const int64_t dof  = node * a.dofs_per_node + a.field_inds[u];
+        if constexpr (!RHS_MODE)
+            if (a.dirichlet != nullptr && a.dirichlet[dof] != 0)
+                continue;
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int r = 0; r < R; ++r)
         {
-            const int64_t dof = node * a.dofs_per_node + a.field_inds[u];
-            if constexpr (!RHS_MODE)
-                if (a.dirichlet != nullptr && a.dirichlet[dof] != 0)
-                    continue;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
+            const double val = (RHS_MODE ? 1. : a.alpha) * B0[(r * U + u) * M3 + i];
+            double* dst = dof < a.n_owned_dofs ? a.y + dof + a.ldy * r : a.yg + (dof - a.n_owned_dofs) + a.ldyg * r;
+            if (a.dbg & 1)
             {
-                const double val = (RHS_MODE ? 1. : a.alpha) * B0[(r * U + u) * M3 + i];
-                double*      dst =
-                    dof < a.n_owned_dofs ? a.y + dof + a.ldy * r : a.yg + (dof - a.n_owned_dofs) + a.ldyg * r;
-                unsafeAtomicAdd(dst, val);
+                if (val == 1.2345e300)
+                    *dst = val;
             }
+            else if (a.dbg & 16)
+                *dst = val;
+            else
+                unsafeAtomicAdd(dst, val);
         }
     }
 }

@@ -55,6 +55,8 @@ def test_single_element_vs_golden(ctx, golden, name):
         assert rel_err(Y1.cpu().numpy()[0], g["y"][:, 0]) < 1e-12
     # more columns than n_rhs is an error (MatrixFreeSystem.hpp:1035-1037)
     mf1 = system.MatrixFreeSystem(mesh, kid, g.get("kparams"), asm_opts=(vo, 0, 0), n_rhs=1)
+    if info["n_fields"]:
+        mf1.set_fields(dev(g["node_fields"].T))
     if R > 1:
         with pytest.raises(system.L3KError, match="columns"):
             mf1.apply(X, Y)

@@ -1,0 +1,56 @@
+"""Kernel micro-benchmark: times the element kernel alone (HIP events on the launch stream) for one shape, with the
+ablation switches of L3K_DEBUG_FLAGS (1 no scatter, 2 no gather loads, 4 no QP stage, 8 no sweeps, 16 plain stores
+instead of atomics).  Usage: python tools/kbench.py --order 6 --ne 32 [--flags 0,1,2,...]"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_one(order, ne, steps, perturb):
+    import numpy as np
+    import torch
+    from l3ster_amd import system
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    U = 4
+    part = system.CubePartition(ne, order, perturb=perturb)
+    mesh = system.DeviceMesh(ctx, part, U, part.dirichlet_mask(U))
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    X = system.synthetic_vector_torch(part.node_grid_id, U, "cuda")
+    Y = torch.zeros_like(X)
+    for _ in range(3):
+        mf.apply_elems(2, X, None, Y, None, 1.0)
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for i in range(steps):
+        e0[i].record()
+        mf.apply_elems(2, X, None, Y, None, 1.0)
+        e1[i].record()
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])
+    dofs = part.n_global_nodes * U
+    print(f"flags={os.environ.get('L3K_DEBUG_FLAGS', '0'):>3} p={order} ne={ne} elems={part.n_elems} dofs={dofs} "
+          f"ms(min/med)={ms.min():.3f}/{np.median(ms):.3f}  DOF/s={dofs / np.median(ms) * 1e3:.3e}  "
+          f"ns/elem={np.median(ms) * 1e6 / part.n_elems:.1f}", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--order", type=int, default=6)
+    ap.add_argument("--ne", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--perturb", type=float, default=0.1)
+    ap.add_argument("--flags", default="0")
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        run_one(a.order, a.ne, a.steps, a.perturb)
+    else:
+        for f in a.flags.split(","):
+            env = dict(os.environ, L3K_DEBUG_FLAGS=f)
+            subprocess.run([sys.executable, __file__, "--child", "--order", str(a.order), "--ne", str(a.ne), "--steps",
+                            str(a.steps), "--perturb", str(a.perturb)], env=env, check=True)
