@@ -143,6 +143,8 @@ struct l3k_mesh
     DevBuf< double >    elem_verts;
     DevBuf< uint8_t >   dirichlet;
     DevBuf< int64_t >   owned_dirichlet_rows;
+    DevBuf< uint8_t >   elem_flags;
+    int64_t             exclusive_begin = 0, exclusive_end = 0;
     int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
     int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
 };
@@ -155,6 +157,7 @@ struct l3k_mf
     std::vector< char > blob;
     int                 field_inds[l3k::dev::max_unknowns];
     DevBuf< double >    tables;
+    std::vector< double > tables_host;
     const double*       fields = nullptr;
     size_t              ldf    = 0;
     double              time   = 0.;
@@ -197,7 +200,11 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.elem_nodes      = m->elem_nodes.ptr;
     a.elem_verts      = m->elem_verts.ptr;
     a.dirichlet       = m->dirichlet.ptr;
+    a.elem_flags      = m->elem_flags.ptr;
+    a.exclusive_node_begin = m->exclusive_begin;
+    a.exclusive_node_end   = m->exclusive_end;
     a.tables          = mf->tables.ptr;
+    a.tables_host     = mf->tables_host.data();
     a.fields          = mf->fields;
     a.ldf             = mf->ldf;
     a.n_owned_dofs    = m->nOwnedDofs();
@@ -447,9 +454,34 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
         return rc;
     if (int rc = m->elem_verts.upload(d->elem_verts, size_t(d->n_elems) * 24, ctx->stream))
         return rc;
+    // nodes referenced by exactly one element (the element-internal nodes of the reference's numbering,
+    // mesh/LocalMeshView.hpp:425-458) can be scattered with plain stores: find the maximal owned tail range
+    {
+        std::vector< uint8_t > count(static_cast< size_t >(n_nodes), 0);
+        for (int64_t i = 0; i < d->n_elems * N; ++i)
+            if (count[d->elem_nodes[i]] < 2)
+                ++count[d->elem_nodes[i]];
+        int64_t b = d->n_owned_nodes;
+        while (b > 0 && count[b - 1] <= 1)
+            --b;
+        m->exclusive_begin = b;
+        m->exclusive_end   = d->n_owned_nodes;
+    }
     std::vector< int64_t > rows;
+    std::vector< uint8_t > flags; // host staging buffers must outlive the stream synchronisation below
     if (d->dirichlet)
     {
+        flags.assign(static_cast< size_t >(d->n_elems), 0);
+        for (int64_t e = 0; e < d->n_elems; ++e)
+            for (int64_t i = 0; i < N && !flags[e]; ++i)
+                for (int k = 0; k < d->dofs_per_node; ++k)
+                    if (d->dirichlet[int64_t(d->elem_nodes[e * N + i]) * d->dofs_per_node + k])
+                    {
+                        flags[e] = 1;
+                        break;
+                    }
+        if (int rc = m->elem_flags.upload(flags.data(), flags.size(), ctx->stream))
+            return rc;
         if (int rc = m->dirichlet.upload(d->dirichlet, size_t(n_nodes * d->dofs_per_node), ctx->stream))
             return rc;
         for (int64_t i = 0; i < d->n_owned_nodes * d->dofs_per_node; ++i) // getOwnedDirichletDofs
@@ -531,7 +563,8 @@ int l3k_mf_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpara
         mf->field_inds[u] = fi;
     }
     L3K_HIP(hipSetDevice(ctx->device));
-    const auto block = l3k::host::deviceTableBlock(mesh->order, nq);
+    mf->tables_host  = l3k::host::deviceTableBlock(mesh->order, nq);
+    const auto& block = mf->tables_host;
     if (int rc = mf->tables.upload(block.data(), block.size(), ctx->stream))
         return rc;
     L3K_HIP(hipStreamSynchronize(ctx->stream));

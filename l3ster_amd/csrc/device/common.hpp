@@ -13,7 +13,10 @@ namespace l3k::dev
 {
 inline constexpr int max_unknowns = 8;
 
-// 1-D tables of one (p, nq) pair in HBM, layout: I[n][nq] | C[nq][nq] | qw[nq] | qx[nq] | D[n][nq] | gll[n]
+// 1-D tables of one (p, nq) pair in HBM, layout: I[n][nq] | C[nq][nq] | qw[nq] | qx[nq] | D[n][nq] | gll[n] |
+// even-odd tables of I (n->nq), C (nq->nq), I^T (nq->n), C^T (nq->nq): for W (nin x nout) with the symmetry
+// W[nin-1-b][nout-1-q] = s*W[b][q] (s = +1 interpolation, -1 derivative) two row-major arrays
+// We, Wo of ceil(nin/2) x ceil(nout/2) each (see host/tables.cpp:evenOddTables and device/sumfact_fast.hpp:sweepEO).
 struct TableLayout
 {
     int n, nq;
@@ -23,7 +26,13 @@ struct TableLayout
     constexpr int offX() const { return offW() + nq; }
     constexpr int offD() const { return offX() + nq; }
     constexpr int offG() const { return offD() + n * nq; }
-    constexpr int size() const { return offG() + n; }
+    constexpr int hn() const { return (n + 1) / 2; }
+    constexpr int hq() const { return (nq + 1) / 2; }
+    constexpr int offEoI() const { return offG() + n; }                    // We | Wo, each hn x hq
+    constexpr int offEoC() const { return offEoI() + 2 * hn() * hq(); }    // each hq x hq
+    constexpr int offEoIt() const { return offEoC() + 2 * hq() * hq(); }   // each hq x hn
+    constexpr int offEoCt() const { return offEoIt() + 2 * hq() * hn(); }  // each hq x hq
+    constexpr int size() const { return offEoCt() + 2 * hq() * hq(); }
 };
 
 // Everything an element kernel needs; passed by value as the kernel argument (scalar loads).
@@ -32,7 +41,10 @@ struct ElemArgs
     const uint32_t* elem_nodes; // [n_elems][N]
     const double*   elem_verts; // [n_elems][8][3]
     const uint8_t*  dirichlet;  // [n_local_dofs] or nullptr
-    const double*   tables;     // TableLayout
+    const uint8_t*  elem_flags; // [n_elems] bit 0: element touches a Dirichlet dof (nullptr when no mask)
+    int64_t         exclusive_node_begin, exclusive_node_end; // nodes in [begin,end) belong to exactly one element
+    const double*   tables;     // TableLayout (device)
+    const double*   tables_host; // the same block in host memory (copied into the kernel arguments of the fast path)
     const double*   fields;     // SoA [F][ldf] or nullptr
     size_t          ldf;
     const double*   x;  // owned rows

@@ -5,6 +5,7 @@
 
 #include "../user_kernels.hpp"
 #include "sumfact_apply.hpp"
+#include "sumfact_fast.hpp"
 
 namespace l3k::dev
 {
@@ -18,6 +19,19 @@ L3K_FOR_EACH_KERNEL(L3K_X)
 #undef L3K_X
 } // namespace l3k::dev
 
+namespace l3k::dev
+{
+// single-column applies use the register-resident pipelined kernel when its working set fits
+template < typename T, int P, int NQ, int R >
+constexpr LaunchFn selectApply()
+{
+    if constexpr (R == 1 && FastCfg< T, P, NQ >::feasible)
+        return &launchSumfactFast< T, P, NQ >;
+    else
+        return &launchSumfactApply< T, P, NQ, R, false >;
+}
+} // namespace l3k::dev
+
 #define L3K_CAT2(a, b) a##b
 #define L3K_CAT(a, b) L3K_CAT2(a, b)
 #define L3K_INSTANTIATE(T, P, NQ, R)                                                                                   \
@@ -28,7 +42,7 @@ L3K_FOR_EACH_KERNEL(L3K_X)
         L3K_CAT(Registrar_, __LINE__)()                                                                                \
         {                                                                                                              \
             ::l3k::dev::registerInstance({::l3k::dev::KernelId< T >::value, P, NQ, R,                                  \
-                                          &::l3k::dev::launchSumfactApply< T, P, NQ, R, false >,                       \
+                                          ::l3k::dev::selectApply< T, P, NQ, R >(),                                  \
                                           &::l3k::dev::launchSumfactApply< T, P, NQ, R, true >, nullptr});            \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \

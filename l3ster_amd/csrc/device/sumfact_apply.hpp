@@ -74,30 +74,44 @@ sweep(const double* __restrict__ src, double* __restrict__ dst, int op_stride, c
     }
 }
 
-// Geometry of a tri-linear hex at reference point (xi, eta, zeta) from its 8 vertices (v = i + 2j + 4k):
-// Jm[s][d] = d x_s / d xi_d  (the transpose convention of algsys/SumFactorization.hpp:716-725), and x itself.
-__device__ __forceinline__ void
-hexGeometry(const double* __restrict__ vs /*[8][3]*/, double xi, double eta, double zeta, double Jm[3][3], double xyz[3])
+// Geometry of a tri-linear hex (8 vertices, v = i + 2j + 4k).  Along an x-pencil (eta, zeta fixed) the map is linear
+// in xi: x = G0 + xi*G1, dx/dxi = G1, dx/deta = G2 + xi*G3, dx/dzeta = G4 + xi*G5 (each a 3-vector), so the 18 pencil
+// coefficients are computed once and every quadrature point costs 9 FMAs.
+__device__ __forceinline__ void hexPencilGeom(const double* __restrict__ vs /*[8][3]*/, double eta, double zeta, double G[6][3])
 {
-    const double l[3][2] = {{.5 * (1. - xi), .5 * (1. + xi)}, {.5 * (1. - eta), .5 * (1. + eta)}, {.5 * (1. - zeta), .5 * (1. + zeta)}};
+    const double le[2] = {.5 * (1. - eta), .5 * (1. + eta)}, lz[2] = {.5 * (1. - zeta), .5 * (1. + zeta)};
 #pragma unroll
     for (int s = 0; s < 3; ++s)
     {
-        double x = 0., dx = 0., dy = 0., dz = 0.;
+        // a[j][k] = mean over i, b[j][k] = half difference over i of the vertex coordinate
+        double a[2][2], b[2][2];
 #pragma unroll
-        for (int v = 0; v < 8; ++v)
-        {
-            const int    i = v & 1, j = (v >> 1) & 1, k = v >> 2;
-            const double c = vs[v * 3 + s];
-            x += c * l[0][i] * l[1][j] * l[2][k];
-            dx += c * (i ? .5 : -.5) * l[1][j] * l[2][k];
-            dy += c * l[0][i] * (j ? .5 : -.5) * l[2][k];
-            dz += c * l[0][i] * l[1][j] * (k ? .5 : -.5);
-        }
-        xyz[s]   = x;
-        Jm[s][0] = dx;
-        Jm[s][1] = dy;
-        Jm[s][2] = dz;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+            {
+                const double c0 = vs[(0 + 2 * j + 4 * k) * 3 + s], c1 = vs[(1 + 2 * j + 4 * k) * 3 + s];
+                a[j][k] = .5 * (c0 + c1);
+                b[j][k] = .5 * (c1 - c0);
+            }
+        G[0][s] = (a[0][0] * le[0] + a[1][0] * le[1]) * lz[0] + (a[0][1] * le[0] + a[1][1] * le[1]) * lz[1];
+        G[1][s] = (b[0][0] * le[0] + b[1][0] * le[1]) * lz[0] + (b[0][1] * le[0] + b[1][1] * le[1]) * lz[1];
+        G[2][s] = .5 * ((a[1][0] - a[0][0]) * lz[0] + (a[1][1] - a[0][1]) * lz[1]);
+        G[3][s] = .5 * ((b[1][0] - b[0][0]) * lz[0] + (b[1][1] - b[0][1]) * lz[1]);
+        G[4][s] = .5 * ((a[0][1] - a[0][0]) * le[0] + (a[1][1] - a[1][0]) * le[1]);
+        G[5][s] = .5 * ((b[0][1] - b[0][0]) * le[0] + (b[1][1] - b[1][0]) * le[1]);
+    }
+}
+// Jm[s][d] = d x_s / d xi_d (the transpose convention of algsys/SumFactorization.hpp:716-725) and x at xi on the pencil
+__device__ __forceinline__ void hexPointOnPencil(const double G[6][3], double xi, double Jm[3][3], double xyz[3])
+{
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+    {
+        xyz[s]   = G[0][s] + xi * G[1][s];
+        Jm[s][0] = G[1][s];
+        Jm[s][1] = G[2][s] + xi * G[3][s];
+        Jm[s][2] = G[4][s] + xi * G[5][s];
     }
 }
 // inverse + determinant of a 3x3 (cofactors), Ji = Jm^{-1}: Ji[d][s] = d xi_d / d x_s
@@ -125,10 +139,8 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
 // On return r0[op], rd[d][op] hold A0^T t and D_d^T t.  RHS_MODE: t = wgt * (f - B x) (rhs with Dirichlet lifting).
 template < typename K, int R, bool RHS_MODE >
 __device__ __forceinline__ void qpStage(const K&      kern,
-                                        const double* vs,
+                                        const double (*G)[3],
                                         double        xi,
-                                        double        eta,
-                                        double        zeta,
                                         double        w_ref,
                                         double        time,
                                         const double* v,
@@ -141,7 +153,7 @@ __device__ __forceinline__ void qpStage(const K&      kern,
     using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, R} >;
 
     double Jm[3][3], Ji[3][3], xyz[3];
-    hexGeometry(vs, xi, eta, zeta, Jm, xyz);
+    hexPointOnPencil(G, xi, Jm, xyz);
     const double det = inverse3(Jm, Ji);
     const double wgt = w_ref * det;
 
@@ -308,7 +320,9 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         }
         const double* qw = a.tables + TL.offW();
         const double* qp = a.tables + TL.offX();
-        qpStage< K, R, RHS_MODE >(kern, vs, qp[qx], qp[qy], qp[qz], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd);
+        double G[6][3];
+        hexPencilGeom(vs, qp[qy], qp[qz], G);
+        qpStage< K, R, RHS_MODE >(kern, G, qp[qx], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd);
 #pragma unroll
         for (int o = 0; o < OPS; ++o)
         {

@@ -145,6 +145,35 @@ std::vector< double > collocDeriv(int nq)
     return C;
 }
 
+// Even-odd split of W (nin x nout, row-major) with W[nin-1-b][nout-1-q] = s*W[b][q]:
+//   out[q]        = A + B,   out[nout-1-q] = s*(A - B),   A = sum_r e[r]*We[r][q],  B = sum_r o[r]*Wo[r][q],
+//   e[r] = in[r] + in[nin-1-r], o[r] = in[r] - in[nin-1-r] (r < nin/2), e[nin/2] = in[nin/2] for odd nin.
+// Same decomposition as algsys/SumFactorization.hpp:88-203 (psi+ / psi-), with the 1/2 folded into the tables.
+void evenOddTables(const std::vector< double >& W, int nin, int nout, bool anti, std::vector< double >& We,
+                   std::vector< double >& Wo)
+{
+    const int hi = nin / 2, ho = nout / 2, ri = (nin + 1) / 2, ro = (nout + 1) / 2;
+    We.assign(size_t(ri) * ro, 0.);
+    Wo.assign(size_t(ri) * ro, 0.);
+    for (int q = 0; q < ro; ++q)
+    {
+        const bool mid_col = (nout % 2) && q == ho;
+        for (int r = 0; r < hi; ++r)
+        {
+            const double a = W[r * nout + q], b = W[(nin - 1 - r) * nout + q];
+            if (mid_col) // out[mid] = sum_r e[r]*W[r][mid] (sym) or sum_r o[r]*W[r][mid] (anti)
+                (anti ? Wo : We)[r * ro + q] = a;
+            else
+            {
+                We[r * ro + q] = .5 * (a + b);
+                Wo[r * ro + q] = .5 * (a - b);
+            }
+        }
+        if (nin % 2)
+            We[hi * ro + q] = (mid_col && anti) ? 0. : W[hi * nout + q];
+    }
+}
+
 std::vector< double > deviceTableBlock(int p, int nq)
 {
     std::vector< double > I, D, qx, qw;
@@ -159,6 +188,23 @@ std::vector< double > deviceTableBlock(int p, int nq)
     out.insert(out.end(), qx.begin(), qx.end());
     out.insert(out.end(), D.begin(), D.end());
     out.insert(out.end(), gll.begin(), gll.end());
+    const int             n = p + 1;
+    std::vector< double > It(size_t(nq) * n), Ct(size_t(nq) * nq), We, Wo;
+    for (int b = 0; b < n; ++b)
+        for (int q = 0; q < nq; ++q)
+            It[q * n + b] = I[b * nq + q];
+    for (int a = 0; a < nq; ++a)
+        for (int q = 0; q < nq; ++q)
+            Ct[q * nq + a] = C[a * nq + q];
+    auto append = [&](const std::vector< double >& W, int nin, int nout, bool anti) {
+        evenOddTables(W, nin, nout, anti, We, Wo);
+        out.insert(out.end(), We.begin(), We.end());
+        out.insert(out.end(), Wo.begin(), Wo.end());
+    };
+    append(I, n, nq, false);
+    append(C, nq, nq, true);
+    append(It, nq, n, false);
+    append(Ct, nq, nq, true);
     return out;
 }
 } // namespace l3k::host

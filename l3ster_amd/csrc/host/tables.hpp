@@ -15,7 +15,9 @@ void lagrange(const std::vector< double >& nodes, double x, double* vals, double
 void basis1d(int p, int nq, std::vector< double >& I, std::vector< double >& D);
 // collocation derivative on the Gauss points: C[q'][q] = l_q''(x_q) for the Lagrange basis l on the nq Gauss points
 std::vector< double > collocDeriv(int nq);
-// device table block in dev::TableLayout order: I | C | qw | qx | D | gll
+void evenOddTables(const std::vector< double >& W, int nin, int nout, bool anti, std::vector< double >& We,
+                   std::vector< double >& Wo);
+// device table block in dev::TableLayout order: I | C | qw | qx | D | gll | even-odd tables of I, C, I^T, C^T
 std::vector< double > deviceTableBlock(int p, int nq);
 } // namespace l3k::host
 #endif
