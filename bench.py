@@ -124,7 +124,7 @@ def main():
         else:  # same three launches as l3k_mf_apply, with events around the element kernel
             mf.scale(Y, 0.0)
             ev0[i].record()
-            mf.apply_elems(2, X, None, Y, None, 1.0)
+            mf.apply_elems(2, X, None, Y, None, 1.0, 0.0)
             ev1[i].record()
             mf.dirichlet_rows(X, Y, 1.0)
 

@@ -126,9 +126,13 @@ int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t 
  * m_import_shared_buf / m_export_shared_buf (:1008-1009), accessed through BorderAccessor semantics
  * (algsys/ComputeValuesAtNodes.hpp:21-50): local dof < n_owned -> owned vector, else ghost buffer.
  *   which: 0 = interior elements, 1 = border elements, 2 = all. */
-int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta);                /* :1038           */
+/* Y <- beta*Y (:1038) on the rows the element kernels ACCUMULATE into.  Rows of nodes that belong to exactly one element
+ * (the element-internal nodes of the reference's numbering, mesh/LocalMeshView.hpp:425-458) are not touched here when
+ * the operator covers all dofs of a node: l3k_mf_apply_elems WRITES alpha*A*x + beta*y there (no atomics, and for
+ * beta = 0 no read), so it must be given the same beta.  Together the two calls equal the reference's scale + scatter. */
+int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta);
 int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg,
-                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha);
+                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha, double beta);
 int l3k_mf_dirichlet_rows(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols,
                           double alpha);                                                        /* :1087-1098      */
 /* comm::Import pack (owner side gathers owned rows through m_owned_inds, comm/ImportExport.hpp:356-372) and

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libl3k.so")
+LIB_PATH = os.environ.get("L3K_LIB") or os.path.join(_HERE, "lib", "libl3k.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -67,7 +67,7 @@ SIGNATURES = {
     "l3k_mf_apply": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double, C.c_double]),
     "l3k_mf_scale": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_double]),
     "l3k_mf_apply_elems": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t,
-                                     C.c_int, C.c_double]),
+                                     C.c_int, C.c_double, C.c_double]),
     "l3k_mf_dirichlet_rows": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double]),
     "l3k_pack_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int64, _vp]),
     "l3k_unpack_add_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, C.c_int]),

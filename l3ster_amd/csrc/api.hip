@@ -161,6 +161,7 @@ struct l3k_mf
     const double*       fields = nullptr;
     size_t              ldf    = 0;
     double              time   = 0.;
+    bool                dense = false, fuse = false;
 };
 
 namespace
@@ -214,7 +215,8 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
         const char* e = std::getenv("L3K_DEBUG_FLAGS");
         return e ? std::atoi(e) : 0;
     }();
-    a.dbg = dbg_flags;
+    a.dbg   = dbg_flags;
+    a.dense = mf->dense;
     for (int u = 0; u < l3k::dev::max_unknowns; ++u)
         a.field_inds[u] = mf->field_inds[u];
     switch (which)
@@ -562,6 +564,11 @@ int l3k_mf_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpara
         }
         mf->field_inds[u] = fi;
     }
+    mf->dense = k->kp.n_unknowns == mesh->dofs_per_node;
+    for (int u = 0; u < k->kp.n_unknowns; ++u)
+        mf->dense = mf->dense && mf->field_inds[u] == u;
+    // rows of nodes touched by one element only are written (not accumulated) by the element kernel, see l3k_mf_scale
+    mf->fuse = mf->dense && mesh->exclusive_end > mesh->exclusive_begin;
     L3K_HIP(hipSetDevice(ctx->device));
     mf->tables_host  = l3k::host::deviceTableBlock(mesh->order, nq);
     const auto& block = mf->tables_host;
@@ -610,16 +617,24 @@ int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta)
         setError("l3k_mf_scale: null argument");
         return -1;
     }
-    const int64_t rows = mf->mesh->nOwnedDofs();
+    const l3k_mesh* m    = mf->mesh;
+    const int64_t   rows = m->nOwnedDofs();
     if (beta == 1. || rows == 0)
         return 0;
-    hipLaunchKernelGGL(scaleKernel, dim3(gridFor(rows)), dim3(256), 0, mf->ctx->stream, d_y, ldy, rows, ncols, beta);
+    // rows of exclusive nodes are left to the element kernel (it writes alpha*A*x + beta*y there)
+    const int64_t r0 = mf->fuse ? m->exclusive_begin * m->dofs_per_node : rows;
+    const int64_t r1 = mf->fuse ? m->exclusive_end * m->dofs_per_node : rows;
+    if (r0 > 0)
+        hipLaunchKernelGGL(scaleKernel, dim3(gridFor(r0)), dim3(256), 0, mf->ctx->stream, d_y, ldy, r0, ncols, beta);
+    if (rows > r1)
+        hipLaunchKernelGGL(scaleKernel, dim3(gridFor(rows - r1)), dim3(256), 0, mf->ctx->stream, d_y + r1, ldy, rows - r1,
+                           ncols, beta);
     L3K_HIP(hipGetLastError());
     return 0;
 }
 
 int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg,
-                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha)
+                       double* d_y, size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha, double beta)
 {
     if (!mf || !d_x || !d_y)
     {
@@ -648,7 +663,9 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     a.ldxg  = ldxg;
     a.ldy   = ldy;
     a.ldyg  = ldyg;
-    a.alpha = alpha;
+    a.alpha     = alpha;
+    a.beta      = beta;
+    a.fuse_beta = mf->fuse;
     const auto* inst = instanceFor(mf, ncols);
     if (!inst)
         return -4;
@@ -685,7 +702,7 @@ int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t 
     }
     if (int rc = l3k_mf_scale(mf, d_y, ldy, ncols, beta))
         return rc;
-    if (int rc = l3k_mf_apply_elems(mf, 2, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha))
+    if (int rc = l3k_mf_apply_elems(mf, 2, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha, beta))
         return rc;
     return l3k_mf_dirichlet_rows(mf, d_x, ldx, d_y, ldy, ncols, alpha);
 }

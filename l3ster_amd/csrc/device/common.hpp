@@ -54,7 +54,8 @@ struct ElemArgs
     size_t          ldx, ldxg, ldy, ldyg;
     int64_t         n_owned_dofs;
     int64_t         elem_begin, elem_count;
-    double          alpha, time;
+    double          alpha, beta, time;
+    int             fuse_beta; // rows of exclusive nodes are written as alpha*A*x + beta*y by the element kernel
     int             dofs_per_node;
     int             field_inds[max_unknowns];
     // diag/rhs mode
@@ -66,6 +67,7 @@ struct ElemArgs
     double* K;
     double* F;
     double* checksum;
+    int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS); 0 in production
 };
 

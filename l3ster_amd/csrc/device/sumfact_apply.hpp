@@ -359,9 +359,8 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         const int     u    = t - i * U;
         const int64_t node = en[i];
         const int64_t dof  = node * a.dofs_per_node + a.field_inds[u];
-        if constexpr (!RHS_MODE)
-            if (a.dirichlet != nullptr && a.dirichlet[dof] != 0)
-                continue;
+        const bool    dir  = !RHS_MODE && a.dirichlet != nullptr && a.dirichlet[dof] != 0;
+        const bool    excl = !RHS_MODE && a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end;
 #pragma unroll
         for (int r = 0; r < R; ++r)
         {
@@ -372,10 +371,15 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
                 if (val == 1.2345e300)
                     *dst = val;
             }
-            else if (a.dbg & 16)
-                *dst = val;
-            else
-                unsafeAtomicAdd(dst, val);
+            else if (excl) // node of this element only: write alpha*A*x + beta*y (see l3k_mf_scale)
+                *dst = (dir ? 0. : val) + (a.beta == 0. ? 0. : a.beta * *dst);
+            else if (!dir)
+            {
+                if (a.dbg & 16)
+                    *dst = val;
+                else
+                    unsafeAtomicAdd(dst, val);
+            }
         }
     }
 }

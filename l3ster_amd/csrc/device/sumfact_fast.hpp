@@ -3,21 +3,28 @@
 // Same mathematics as sumfact_apply.hpp (collocation-derivative form of evalLocalOperatorSumFact,
 // algsys/SumFactorization.hpp:882-917, fused with gatherSumFact / scatterSumFact, algsys/MatrixFreeSystem.hpp:421-537)
 // re-organised for the CDNA4 execution model, where this kernel is FP64-VALU bound (about 250 fp64 flop per dof,
-// SURVEY.md D9) with LDS store bandwidth (~85 B/clk/CU) as the second limiter:
+// SURVEY.md D9) with the LDS (store path ~85 B/clk/CU) as the second limiter:
 //
-//  * one "team" of M*M threads (M = max(n, nq)) per element, EB elements per workgroup so that the 64-wide waves are
-//    ~96 % full (p = 6: 5 elements = 245 of 256 lanes); every thread owns ONE 1-D pencil of ALL fields in registers,
-//    so each sweep is register-only FMAs with the even-odd decomposition (the reference's own flop cut,
-//    algsys/SumFactorization.hpp:88-343: 37 instead of 49 instructions per 7-point pencil), and the LDS only carries
-//    the pencil re-orientations (two buffers per element);
+//  * one WAVE owns its element(s): a "team" of M*M lanes (M = max(n, nq)) per element, 64 / (M*M) elements per wave
+//    (p = 6: 49 of 64 lanes; p = 4: 2 x 25; p = 3: 4 x 16).  A workgroup is a single wave, so there is NO workgroup
+//    barrier anywhere: LDS instructions of one wave execute in order, and the 5-7 resident waves of a CU drift apart,
+//    which overlaps one wave's LDS phases with another wave's FMA phases (with 256-thread workgroups in lockstep the two
+//    pipes were each ~35 % busy and serialised: profiles/r01_pmc_fast_v2b_compute_only.txt);
+//  * every lane owns ONE 1-D pencil of ALL fields in registers, so each sweep is register-only FMAs with the even-odd
+//    decomposition (the reference's own flop cut, algsys/SumFactorization.hpp:88-343: 37 instead of 49 instructions per
+//    7-point pencil); the LDS only carries the pencil re-orientations (two buffers per element), with the fields
+//    interleaved in pairs so that every LDS access is 16 bytes wide;
 //  * the global gather goes straight to registers one element ahead (node ids two ahead) and stays in flight behind the
-//    whole compute phase of the current element; one persistent workgroup per CU walks the element batches;
-//  * the scatter uses plain stores for nodes touched by exactly one element (the element-internal nodes of the
-//    reference's numbering, mesh/LocalMeshView.hpp:425-458) and f64 atomics only for shared nodes.
+//    whole compute phase of the current element; waves are persistent and walk the element batches;
+//  * the result is staged once through LDS into dof order so that the scatter's wave-instructions cover contiguous
+//    bytes; nodes touched by exactly one element (the element-internal nodes of the reference's numbering,
+//    mesh/LocalMeshView.hpp:425-458) use plain read-modify-write, only shared nodes use f64 atomics.
 #ifndef L3K_DEVICE_SUMFACT_FAST_HPP
 #define L3K_DEVICE_SUMFACT_FAST_HPP
 
 #include "sumfact_apply.hpp"
+
+#include <cstdlib>
 
 namespace l3k::dev
 {
@@ -80,12 +87,6 @@ struct FastTables
     double               eoI[2 * HN * HQ], eoC[2 * HQ * HQ], eoIt[2 * HQ * HN], eoCt[2 * HQ * HQ], qw[NQ], qx[NQ];
 };
 
-// workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() would also wait
-// for vmcnt(0) and drain the next element's global loads that are deliberately left in flight.
-__device__ __forceinline__ void ldsBarrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 // A zero the compiler cannot see through, in an SGPR.  Table pointers are offset by a fresh one in every stage so that
 // the coefficient loads (s_load from the kernel-argument segment) are re-issued next to their use instead of being
 // hoisted out of the element loop all at once, which would need ~280 SGPRs and spill them to VGPR lanes.
@@ -95,34 +96,54 @@ __device__ __forceinline__ int opaqueZero()
     asm volatile("s_mov_b32 %0, 0" : "=s"(z));
     return z;
 }
+// Stage separator inside a wave: LDS instructions of one wave execute in issue order, so no s_barrier is needed; this
+// only stops the COMPILER from moving LDS accesses across the stage boundary.
+__device__ __forceinline__ void stageFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template < typename K, int P, int NQ >
 struct FastCfg
 {
-    static constexpr int N1 = P + 1, M = cmax(N1, NQ), TEAM = M * M, M3 = M * M * M;
+    static constexpr int N1 = P + 1, M = cmax(N1, NQ), TEAM = M * M, NN = N1 * N1 * N1;
     static constexpr int U = K::params.n_unknowns, F = K::params.n_fields, NF = U + F;
-    // elements per workgroup: as many teams as fit 256 threads (p=6: 5 -> 245 lanes; p=4: 10 -> 250 lanes)
-    static constexpr int    EB       = 256 / TEAM > 0 ? 256 / TEAM : 1;
-    static constexpr int    NT       = ((EB * TEAM + 63) / 64) * 64;
-    static constexpr size_t lds      = sizeof(double) * (size_t(EB) * (2 * NF * M3 + 24));
-    static constexpr bool   feasible = lds <= 160 * 1024 && NT <= 1024 && NF * cmax(N1, NQ) <= 64;
+    static constexpr int NG = (NF + 1) / 2; // field groups of 2 (16-byte LDS accesses); last may be half used
+    static constexpr int UG = (U + 1) / 2;
+    // LDS array strides: point (c, b, a) lives at a*PS + b*M + c (in 16-byte units within a field group)
+    static constexpr int PS = M * M, OS = PS * M;
+    static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
+    // per team: bufA | bufB (NG groups of OS double2 each) | vertices
+    static constexpr int    BUF_D    = 2 * NG * OS;
+    static constexpr int    TEAM_D   = 2 * BUF_D + 24;
+    static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D;
+    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUF_D;
 };
 
+#ifndef L3K_FAST_MIN_WAVES
+#define L3K_FAST_MIN_WAVES 2
+#endif
 template < typename K, int P, int NQ >
-__global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
-                                                                                  const FastTables< P + 1, NQ > tab)
+__global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
+                                                        const FastTables< P + 1, NQ > tab)
 {
     using Cfg = FastCfg< K, P, NQ >;
-    constexpr int         N1 = Cfg::N1, M3 = Cfg::M3, TEAM = Cfg::TEAM, EB = Cfg::EB;
-    constexpr int         U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NN = N1 * N1 * N1;
+    constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
+    constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
+    auto          at = [](int c, int b, int a_) { return a_ * PS + b * M + c; };
 
     extern __shared__ double lds[];
-    const int                tid  = threadIdx.x;
-    const int                team = tid / TEAM, l = tid - team * TEAM;
-    const bool               live = team < EB;
-    double* const            bufA = lds + size_t(team < EB ? team : 0) * (2 * NF * M3 + 24);
-    double* const            bufB = bufA + NF * M3;
-    double* const            vs   = bufB + NF * M3; // [8][3]
+    const int                lane = threadIdx.x;
+    const int                team = lane / TEAM, l = lane - team * TEAM;
+    const bool               live = team < EW;
+    if (!live || l >= cmax(N1 * N1, cmax(N1 * NQ, NQ * NQ)))
+        return; // single-wave workgroup without barriers: idle lanes simply retire, EXEC stays fixed from here on
+    double* const            base = lds + size_t(team) * Cfg::TEAM_D;
+    double2* const           bufA = reinterpret_cast< double2* >(base);
+    double2* const           bufB = reinterpret_cast< double2* >(base + Cfg::BUF_D);
+    double* const            vs   = base + 2 * Cfg::BUF_D; // [8][3]
 
     const double* const eoI  = tab.eoI;
     const double* const eoC  = tab.eoC;
@@ -131,22 +152,27 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
     const double* const qw   = tab.qw;
     const double* const qp   = tab.qx;
 
-    // pencil coordinates of this thread in the different stage grids (a fastest)
-    const int  i1 = l % N1, j1 = l / N1;   // (N1 x N1) grid: load / z-sweep / final z-sweep + scatter
-    const bool on_nn = live && l < N1 * N1;
-    const int  iq = l % N1, kq = l / N1;   // (N1 x NQ) grid: y-sweeps at node-x
-    const bool on_nq = live && l < N1 * NQ;
-    const int  qa = l % NQ, qb = l / NQ;   // (NQ x NQ) grid
-    const bool on_qq = live && l < NQ * NQ;
+    // pencil coordinates of this lane in the different stage grids (first index fastest)
+    const int  i1 = l % N1, j1 = l / N1; // (N1 x N1) grid: gather / z-sweep / final z-sweep
+    const bool on_nn = N1 == NQ ? true : l < N1 * N1;
+    const int  iq = l % N1, kq = l / N1; // (N1 x NQ) grid: y-sweeps at node-x
+    const bool on_nq = N1 == NQ ? true : l < N1 * NQ;
+    const int  qa = l % NQ, qb = l / NQ; // (NQ x NQ) grid
+    const bool on_qq = N1 == NQ ? true : l < NQ * NQ;
+
+    // field-group accessors: group g holds fields 2g, 2g+1 (the second may be unused padding)
+    auto ldg = [&](const double2* buf, int g, int idx) { return buf[g * OS + idx]; };
+    auto stg = [&](double2* buf, int g, int idx, double x0, double x1) { buf[g * OS + idx] = make_double2(x0, x1); };
 
     // ---- software pipeline state: node ids two batches ahead, x values one batch ahead
-    uint32_t ids_cur[N1], ids_nxt[N1];
-    double   xn[N1][U > 0 ? U : 1];
-    double   fn[N1][F > 0 ? F : 1];
-    uint32_t dm_nxt[N1];
-    auto     elemOf = [&](int64_t batch) { return a.elem_begin + batch * EB + team; };
-    auto     valid  = [&](int64_t batch) { return batch < n_batches && on_nn && (batch * EB + team) < a.elem_count; };
-    auto     loadIds = [&](int64_t batch, uint32_t (&ids)[N1]) {
+    uint32_t      ids_cur[N1], ids_nxt[N1];
+    double        xn[N1][U];
+    double        fn[N1][F > 0 ? F : 1];
+    uint32_t      dm_nxt[N1];
+    const int64_t n_owned_nodes = a.n_owned_dofs / a.dofs_per_node;
+    auto          elemOf = [&](int64_t batch) { return a.elem_begin + batch * EW + team; };
+    auto valid   = [&](int64_t batch) { return batch < n_batches && on_nn && (batch * EW + team) < a.elem_count; };
+    auto loadIds = [&](int64_t batch, uint32_t (&ids)[N1]) {
         if (valid(batch))
         {
             const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + i1 + N1 * j1;
@@ -159,15 +185,47 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
         if (!valid(batch))
             return;
         const bool flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[elemOf(batch)] != 0;
+        if constexpr (U % 2 == 0)
+            if (a.dense)
+            {
+                // node-interleaved dofs with the kernel's unknowns = all dofs of a node: 16-byte vector loads, adjacent
+                // lanes read adjacent nodes (dofs/NodeToDofMap.hpp:250-264 layout)
+#pragma unroll
+                for (int k = 0; k < N1; ++k)
+                {
+                    const int64_t node = ids[k];
+                    const double* p    = node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
+#pragma unroll
+                    for (int hh = 0; hh < U / 2; ++hh)
+                    {
+                        const double2 t = (a.dbg & 2) ? make_double2(1e-9 * double(node), 1e-9)
+                                                      : *reinterpret_cast< const double2* >(p + 2 * hh);
+                        xn[k][2 * hh]     = t.x;
+                        xn[k][2 * hh + 1] = t.y;
+                    }
+                    uint32_t dm = 0;
+                    if (flagged)
+                    {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            dm |= uint32_t(a.dirichlet[node * U + u] != 0) << u;
+                    }
+                    dm_nxt[k] = dm;
+#pragma unroll
+                    for (int f = 0; f < F; ++f)
+                        fn[k][f] = a.fields[node + f * a.ldf];
+                }
+                return;
+            }
 #pragma unroll
         for (int k = 0; k < N1; ++k)
         {
-            const int64_t base = int64_t(ids[k]) * a.dofs_per_node;
-            uint32_t      dm   = 0;
+            const int64_t nbase = int64_t(ids[k]) * a.dofs_per_node;
+            uint32_t      dm    = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
-                const int64_t dof = base + a.field_inds[u];
+                const int64_t dof = nbase + a.field_inds[u];
                 xn[k][u] = (a.dbg & 2) ? double(dof) * 1e-9 : (dof < a.n_owned_dofs ? a.x[dof] : a.xg[dof - a.n_owned_dofs]);
                 if (flagged)
                     dm |= uint32_t(a.dirichlet[dof] != 0) << u;
@@ -186,89 +244,103 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
 
     for (; batch < n_batches; batch += gridDim.x)
     {
-        const bool act = (batch * EB + team) < a.elem_count; // this team has an element in this batch
+        const bool act = (batch * EW + team) < a.elem_count; // this team has an element in this batch
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
-        double   u0[N1][NF];
-        uint32_t ids_sc[N1], dm_sc[N1];
+        double u0[N1][2 * NG];
         if (on_nn && act)
         {
 #pragma unroll
             for (int k = 0; k < N1; ++k)
             {
-                ids_sc[k] = ids_cur[k];
-                dm_sc[k]  = dm_nxt[k];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     u0[k][u] = (dm_nxt[k] >> u) & 1u ? 0. : xn[k][u];
 #pragma unroll
                 for (int f = 0; f < F; ++f)
                     u0[k][U + f] = fn[k][f];
+                if constexpr (NF % 2)
+                    u0[k][NF] = 0.;
             }
         }
-        if (live && act)
+        if (act)
             for (int t = l; t < 24; t += TEAM)
                 vs[t] = a.elem_verts[elemOf(batch) * 24 + t];
-        // rotate the id pipeline and launch the next loads: they stay in flight behind this batch's compute
+        // rotate the id pipeline; the next batch's ids are already here, its x values are requested further down (once
+        // the quadrature-point registers are dead) and stay in flight behind the tail of this batch
 #pragma unroll
         for (int k = 0; k < N1; ++k)
             ids_cur[k] = ids_nxt[k];
-        loadX(batch + gridDim.x, ids_cur);
         loadIds(batch + 2 * int64_t(gridDim.x), ids_nxt);
 
-        // ---- S1: z interpolation in registers; T1: write [op][qz][j][i] into bufA
+        // ---- S1: z interpolation in registers; write (c=i, b=j, a=qz) into bufA
         if (on_nn && act)
         {
             const double* tI = eoI + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int g = 0; g < NG; ++g)
             {
-                double in[N1], out[NQ];
+                double in0[N1], in1[N1], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int k = 0; k < N1; ++k)
-                    in[k] = u0[k][o];
-                sweepEO< N1, NQ, false, false >(in, out, tI);
+                {
+                    in0[k] = u0[k][2 * g];
+                    in1[k] = u0[k][2 * g + 1];
+                }
+                sweepEO< N1, NQ, false, false >(in0, o0, tI);
+                sweepEO< N1, NQ, false, false >(in1, o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    bufA[o * M3 + (q * N1 + j1) * N1 + i1] = out[q];
+                    stg(bufA, g, at(i1, j1, q), o0[q], o1[q]);
             }
         }
-        ldsBarrier();
-        // ---- S2: y interpolation, thread (i, qz): bufA -> bufB [op][qz][qy][i]
+        stageFence();
+        // ---- S2: y interpolation, lane (i, qz): bufA (c=i, b=j, a=qz) -> bufB (c=i, b=qy, a=qz)
         if (on_nq && act)
         {
             const double* tI = eoI + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int g = 0; g < NG; ++g)
             {
-                double in[N1], out[NQ];
+                double in0[N1], in1[N1], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
-                    in[j] = bufA[o * M3 + (kq * N1 + j) * N1 + iq];
-                sweepEO< N1, NQ, false, false >(in, out, tI);
+                {
+                    const double2 t = ldg(bufA, g, at(iq, j, kq));
+                    in0[j] = t.x;
+                    in1[j] = t.y;
+                }
+                sweepEO< N1, NQ, false, false >(in0, o0, tI);
+                sweepEO< N1, NQ, false, false >(in1, o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    bufB[o * M3 + (kq * NQ + q) * N1 + iq] = out[q];
+                    stg(bufB, g, at(iq, q, kq), o0[q], o1[q]);
             }
         }
-        ldsBarrier();
-        // ---- S3/S4: x interpolation + xi-derivative, thread (qy, qz) = (qa, qb); values to bufA [op][qz][qy][qx]
-        double v[NQ][NF], dxi[NQ][NF];
+        stageFence();
+        // ---- S3/S4: x interpolation + xi-derivative, lane (qy, qz) = (qa, qb); values to bufA (c=qx, b=qy, a=qz)
+        double v[NQ][2 * NG], dxi[NQ][2 * NG];
         if (on_qq && act)
         {
             const double* tI = eoI + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int g = 0; g < NG; ++g)
             {
-                double in[N1], out[NQ];
+                double in0[N1], in1[N1], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
-                    in[i] = bufB[o * M3 + (qb * NQ + qa) * N1 + i];
-                sweepEO< N1, NQ, false, false >(in, out, tI);
+                {
+                    const double2 t = ldg(bufB, g, at(i, qa, qb));
+                    in0[i] = t.x;
+                    in1[i] = t.y;
+                }
+                sweepEO< N1, NQ, false, false >(in0, o0, tI);
+                sweepEO< N1, NQ, false, false >(in1, o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
-                    v[q][o] = out[q];
-                    bufA[o * M3 + (qb * NQ + qa) * NQ + q] = out[q];
+                    v[q][2 * g]     = o0[q];
+                    v[q][2 * g + 1] = o1[q];
+                    stg(bufA, g, at(q, qa, qb), o0[q], o1[q]);
                 }
             }
             const double* tC = eoC + opaqueZero();
@@ -285,43 +357,53 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
                     dxi[q][o] = der[q];
             }
         }
-        ldsBarrier();
-        // ---- S5: eta-derivative, thread (qx, qz) = (qa, qb): y-pencils of bufA -> bufB
+        stageFence();
+        // ---- S5: eta-derivative, lane (qx, qz) = (qa, qb): y-pencils of bufA -> bufB
         if (on_qq && act)
         {
             const double* tC = eoC + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int g = 0; g < NG; ++g)
             {
-                double in[NQ], out[NQ];
+                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    in[q] = bufA[o * M3 + (qb * NQ + q) * NQ + qa];
-                sweepEO< NQ, NQ, true, false >(in, out, tC);
+                {
+                    const double2 t = ldg(bufA, g, at(qa, q, qb));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
+                }
+                sweepEO< NQ, NQ, true, false >(in0, o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1, o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    bufB[o * M3 + (qb * NQ + q) * NQ + qa] = out[q];
+                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
             }
         }
-        ldsBarrier();
-        // ---- S6: zeta-derivative in place in bufA, thread (qx, qy) = (qa, qb)
+        stageFence();
+        // ---- S6: zeta-derivative in place in bufA, lane (qx, qy) = (qa, qb)
         if (on_qq && act)
         {
             const double* tC = eoC + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int g = 0; g < NG; ++g)
             {
-                double in[NQ], out[NQ];
+                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    in[q] = bufA[o * M3 + (q * NQ + qb) * NQ + qa];
-                sweepEO< NQ, NQ, true, false >(in, out, tC);
+                {
+                    const double2 t = ldg(bufA, g, at(qa, qb, q));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
+                }
+                sweepEO< NQ, NQ, true, false >(in0, o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1, o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    bufA[o * M3 + (q * NQ + qb) * NQ + qa] = out[q];
+                    stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
             }
         }
-        ldsBarrier();
+        stageFence();
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
         if (on_qq && act)
         {
@@ -333,12 +415,22 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
             {
                 double vv[NF], dv[3][NF], r0[U], rd[3][U];
 #pragma unroll
+                for (int g = 0; g < NG; ++g)
+                {
+                    const double2 te = ldg(bufB, g, at(q, qa, qb)), tz = ldg(bufA, g, at(q, qa, qb));
+                    dv[1][2 * g] = te.x;
+                    dv[2][2 * g] = tz.x;
+                    if (2 * g + 1 < NF)
+                    {
+                        dv[1][2 * g + 1] = te.y;
+                        dv[2][2 * g + 1] = tz.y;
+                    }
+                }
+#pragma unroll
                 for (int o = 0; o < NF; ++o)
                 {
                     vv[o]    = v[q][o];
                     dv[0][o] = dxi[q][o];
-                    dv[1][o] = bufB[o * M3 + (qb * NQ + qa) * NQ + q];
-                    dv[2][o] = bufA[o * M3 + (qb * NQ + qa) * NQ + q];
                 }
                 qpStage< K, 1, false >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd);
 #pragma unroll
@@ -346,144 +438,193 @@ __global__ __launch_bounds__((FastCfg< K, P, NQ >::NT)) void sumfactFastKernel(c
                 {
                     v[q][o]   = r0[o];
                     dxi[q][o] = rd[0][o];
-                    bufB[o * M3 + (qb * NQ + qa) * NQ + q] = rd[1][o];
-                    bufA[o * M3 + (qb * NQ + qa) * NQ + q] = rd[2][o];
+                }
+#pragma unroll
+                for (int g = 0; g < UG; ++g)
+                {
+                    stg(bufB, g, at(q, qa, qb), rd[1][2 * g], 2 * g + 1 < U ? rd[1][2 * g + 1] : 0.);
+                    stg(bufA, g, at(q, qa, qb), rd[2][2 * g], 2 * g + 1 < U ? rd[2][2 * g + 1] : 0.);
                 }
             }
         }
-        ldsBarrier();
-        // ---- S8: C^T along eta in place in bufB (thread (qx,qz)); S9: C^T along zeta in place in bufA (thread (qx,qy))
+        stageFence();
+        // ---- S8: C^T along eta in place in bufB (lane (qx,qz)); S9: C^T along zeta in place in bufA (lane (qx,qy))
         if (on_qq && act)
         {
             const double* tCt = eoCt + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < U; ++o)
+            for (int g = 0; g < UG; ++g)
             {
-                double in[NQ], out[NQ];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    in[q] = bufB[o * M3 + (qb * NQ + q) * NQ + qa];
-                sweepEO< NQ, NQ, true, false >(in, out, tCt);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    bufB[o * M3 + (qb * NQ + q) * NQ + qa] = out[q];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    in[q] = bufA[o * M3 + (q * NQ + qb) * NQ + qa];
-                sweepEO< NQ, NQ, true, false >(in, out, tCt);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    bufA[o * M3 + (q * NQ + qb) * NQ + qa] = out[q];
-            }
-        }
-        ldsBarrier();
-        // ---- x-pencil (qy,qz): w = r0 + C^T r1 + g2 + g3, then I^T along x -> h[ix]
-        double h[N1][U];
-        if (on_qq && act)
-        {
-            const double* tCt = eoCt + opaqueZero();
-#pragma unroll
-            for (int o = 0; o < U; ++o)
-            {
-                double r1[NQ], w[NQ];
+                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
-                    r1[q] = dxi[q][o];
-                    w[q]  = v[q][o] + bufB[o * M3 + (qb * NQ + qa) * NQ + q] + bufA[o * M3 + (qb * NQ + qa) * NQ + q];
+                    const double2 t = ldg(bufB, g, at(qa, q, qb));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, true >(r1, w, tCt);
+                sweepEO< NQ, NQ, true, false >(in0, o0, tCt);
+                sweepEO< NQ, NQ, true, false >(in1, o1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    v[q][o] = w[q];
+                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                {
+                    const double2 t = ldg(bufA, g, at(qa, qb, q));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
+                }
+                sweepEO< NQ, NQ, true, false >(in0, o0, tCt);
+                sweepEO< NQ, NQ, true, false >(in1, o1, tCt);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
+            }
+        }
+        stageFence();
+        // ---- x-pencil (qy,qz): w = r0 + C^T r1 + g2 + g3, then I^T along x -> bufB (c=ix, b=qy, a=qz)
+        if (on_qq && act)
+        {
+            const double* tCt = eoCt + opaqueZero();
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+            {
+                double r10[NQ], r11[NQ], w0[NQ], w1[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                {
+                    const double2 te = ldg(bufB, g, at(q, qa, qb)), tz = ldg(bufA, g, at(q, qa, qb));
+                    r10[q] = dxi[q][2 * g];
+                    r11[q] = dxi[q][2 * g + 1];
+                    w0[q]  = v[q][2 * g] + te.x + tz.x;
+                    w1[q]  = v[q][2 * g + 1] + te.y + tz.y;
+                }
+                sweepEO< NQ, NQ, true, true >(r10, w0, tCt);
+                sweepEO< NQ, NQ, true, true >(r11, w1, tCt);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                {
+                    v[q][2 * g]     = w0[q];
+                    v[q][2 * g + 1] = w1[q];
+                }
             }
             const double* tIt = eoIt + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < U; ++o)
+            for (int g = 0; g < UG; ++g)
             {
-                double w[NQ], out[N1];
+                double w0[NQ], w1[NQ], o0[N1], o1[N1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    w[q] = v[q][o];
-                sweepEO< NQ, N1, false, false >(w, out, tIt);
+                {
+                    w0[q] = v[q][2 * g];
+                    w1[q] = v[q][2 * g + 1];
+                }
+                sweepEO< NQ, N1, false, false >(w0, o0, tIt);
+                sweepEO< NQ, N1, false, false >(w1, o1, tIt);
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
-                    h[i][o] = out[i];
+                    stg(bufB, g, at(i, qa, qb), o0[i], o1[i]);
             }
         }
-        if constexpr (N1 != NQ)
-            ldsBarrier(); // rows of different length: finish all reads of bufB before re-laying it out
-        if (on_qq && act)
-        {
-#pragma unroll
-            for (int o = 0; o < U; ++o)
-#pragma unroll
-                for (int i = 0; i < N1; ++i)
-                    bufB[o * M3 + (qb * NQ + qa) * N1 + i] = h[i][o];
-        }
-        ldsBarrier();
-        // ---- I^T along y, thread (ix, qz) = (iq, kq): bufB [op][qz][qy][ix] -> bufA [op][qz][iy][ix]
+        stageFence();
+        loadX(batch + gridDim.x, ids_cur); // prefetch: consumed at the top of the next iteration
+        // ---- I^T along y, lane (ix, qz) = (iq, kq): bufB (c=ix, b=qy, a=qz) -> bufA (c=ix, b=iy, a=qz)
         if (on_nq && act)
         {
             const double* tIt = eoIt + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < U; ++o)
+            for (int g = 0; g < UG; ++g)
             {
-                double in[NQ], out[N1];
+                double in0[NQ], in1[NQ], o0[N1], o1[N1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    in[q] = bufB[o * M3 + (kq * NQ + q) * N1 + iq];
-                sweepEO< NQ, N1, false, false >(in, out, tIt);
+                {
+                    const double2 t = ldg(bufB, g, at(iq, q, kq));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
+                }
+                sweepEO< NQ, N1, false, false >(in0, o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1, o1, tIt);
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
-                    bufA[o * M3 + (kq * N1 + j) * N1 + iq] = out[j];
+                    stg(bufA, g, at(iq, j, kq), o0[j], o1[j]);
             }
         }
-        ldsBarrier();
-        // ---- I^T along z in registers, thread (ix, iy) = (i1, j1), then scatter (scatterSumFact, :494-537)
+        stageFence();
+        // ---- I^T along z in registers, lane (ix, iy) = (i1, j1); stage the result in bufB as [node][unknown]
         if (on_nn && act)
         {
-            double ye[N1][U];
             const double* tIt = eoIt + opaqueZero();
+            double*       sb  = reinterpret_cast< double* >(bufB);
 #pragma unroll
-            for (int o = 0; o < U; ++o)
+            for (int g = 0; g < UG; ++g)
             {
-                double in[NQ], out[N1];
+                double in0[NQ], in1[NQ], o0[N1], o1[N1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    in[q] = bufA[o * M3 + (q * N1 + j1) * N1 + i1];
-                sweepEO< NQ, N1, false, false >(in, out, tIt);
+                {
+                    const double2 t = ldg(bufA, g, at(i1, j1, q));
+                    in0[q] = t.x;
+                    in1[q] = t.y;
+                }
+                sweepEO< NQ, N1, false, false >(in0, o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1, o1, tIt);
 #pragma unroll
                 for (int k = 0; k < N1; ++k)
-                    ye[k][o] = out[k];
-            }
-#pragma unroll
-            for (int k = 0; k < N1; ++k)
-            {
-                const int64_t node      = ids_sc[k];
-                const int64_t base      = node * a.dofs_per_node;
-                const bool    exclusive = node >= a.exclusive_node_begin && node < a.exclusive_node_end;
-#pragma unroll
-                for (int o = 0; o < U; ++o)
                 {
-                    if ((dm_sc[k] >> o) & 1u)
-                        continue;
-                    const int64_t dof = base + a.field_inds[o];
-                    const double  val = a.alpha * ye[k][o];
-                    double*       dst = dof < a.n_owned_dofs ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                    if (a.dbg & 1)
+                    double* dstl = sb + (i1 + N1 * (j1 + N1 * k)) * U + 2 * g;
+                    if constexpr (U % 2 == 0)
+                        *reinterpret_cast< double2* >(dstl) = make_double2(a.alpha * o0[k], a.alpha * o1[k]);
+                    else
                     {
-                        if (val == 1.2345e300)
-                            *dst = val;
+                        dstl[0] = a.alpha * o0[k];
+                        if (2 * g + 1 < U)
+                            dstl[1] = a.alpha * o1[k];
                     }
-                    else if (exclusive || (a.dbg & 16))
-                        *dst += val; // touched by this element only: no atomic needed
+                }
+            }
+        }
+        stageFence();
+        // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
+        // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
+        if (act)
+        {
+            const double*   sb      = reinterpret_cast< const double* >(bufB);
+            const int64_t   el      = elemOf(batch);
+            const uint32_t* en      = a.elem_nodes + el * NN;
+            const bool      flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[el] != 0;
+            for (int t = l; t < NN * U; t += TEAM) // kept rolled: unrolling the 28 rounds costs registers (spills)
+            {
+                const int     nl   = t / U;
+                const int     o    = t - nl * U;
+                const int64_t node = en[nl];
+                const int64_t dof  = node * a.dofs_per_node + a.field_inds[o];
+                const bool    dir  = flagged && a.dirichlet[dof] != 0;
+                const double  val  = sb[t];
+                double*       dst  = dof < a.n_owned_dofs ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                if (a.dbg & 1)
+                {
+                    if (val == 1.2345e300)
+                        *dst = val;
+                }
+                else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
+                {
+                    // touched by this element only: y = alpha*(A x) + beta*y written here, no atomic, and for beta = 0
+                    // no read either (these rows are skipped by the pre-scaling pass, l3k_mf_scale)
+                    const double contrib = dir ? 0. : val; // Dirichlet dofs are skipped (MatrixFreeSystem.hpp:517-536)
+                    *dst = a.beta == 0. ? contrib : contrib + a.beta * *dst;
+                }
+                else if (!dir)
+                {
+                    if (a.dbg & 16)
+                        *dst += val;
                     else
                         unsafeAtomicAdd(dst, val);
                 }
             }
         }
-        ldsBarrier(); // bufA is rewritten by the next batch's T1
+        stageFence(); // the buffers are rewritten by the next batch
     }
 }
 
@@ -498,6 +639,7 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
     auto        kernel   = sumfactFastKernel< K, P, NQ >;
     static int  n_cus    = 0;
+    static int  waves_cu = 0;
     static bool attr_set = false;
     if (!attr_set)
     {
@@ -515,23 +657,27 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
             setError("hipGetDeviceProperties failed");
             return -3;
         }
-        n_cus    = prop.multiProcessorCount;
+        n_cus = prop.multiProcessorCount;
+        // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the 256-VGPR budget (2 per SIMD)
+        int by_lds = int((160 * 1024) / Cfg::lds);
+        waves_cu   = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+        if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
+            waves_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_cu;
         attr_set = true;
     }
-    const int64_t n_batches      = (a.elem_count + Cfg::EB - 1) / Cfg::EB;
-    const int     blocks_per_cu  = int((160 * 1024) / Cfg::lds) > 0 ? int((160 * 1024) / Cfg::lds) : 1;
-    const int64_t max_blocks     = int64_t(n_cus) * blocks_per_cu;
-    const unsigned grid          = static_cast< unsigned >(n_batches < max_blocks ? n_batches : max_blocks);
-    constexpr TableLayout        TL{P + 1, NQ};
-    FastTables< P + 1, NQ >      tab;
-    const double*                th = a.tables_host;
+    const int64_t  n_batches  = (a.elem_count + Cfg::EW - 1) / Cfg::EW;
+    const int64_t  max_blocks = int64_t(n_cus) * waves_cu;
+    const unsigned grid       = static_cast< unsigned >(n_batches < max_blocks ? n_batches : max_blocks);
+    constexpr TableLayout   TL{P + 1, NQ};
+    FastTables< P + 1, NQ > tab;
+    const double*           th = a.tables_host;
     __builtin_memcpy(tab.eoI, th + TL.offEoI(), sizeof tab.eoI);
     __builtin_memcpy(tab.eoC, th + TL.offEoC(), sizeof tab.eoC);
     __builtin_memcpy(tab.eoIt, th + TL.offEoIt(), sizeof tab.eoIt);
     __builtin_memcpy(tab.eoCt, th + TL.offEoCt(), sizeof tab.eoCt);
     __builtin_memcpy(tab.qw, th + TL.offW(), sizeof tab.qw);
     __builtin_memcpy(tab.qx, th + TL.offX(), sizeof tab.qx);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::lds, stream, a, kern, n_batches, tab);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, tab);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
     {

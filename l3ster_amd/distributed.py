@@ -73,14 +73,14 @@ class DistributedOperator:
             recv_targets.append(tgt)
             ops.append(dist.P2POp(dist.irecv, tgt, nb, self.group))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        be.apply_elems(0, X, None, Y, None, alpha)  # interior: overlaps the exchange
+        be.apply_elems(0, X, None, Y, None, alpha, beta)  # interior: overlaps the exchange
         for r in reqs:
             r.wait()
         if nc > 1:
             for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
                 xg[:, g0:g1].copy_(stage)
         # ---- border elements, then export: sharer -> owner
-        be.apply_elems(1, X, xg, Y, yg, alpha)
+        be.apply_elems(1, X, xg, Y, yg, alpha, beta)
         ops = []
         for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
             if nc == 1:

@@ -265,13 +265,14 @@ class MatrixFreeSystem:
         nc, ldy = self._cols(Y)
         check(capi.load().l3k_mf_scale(self._h, _ptr(Y), ldy, nc, beta))
 
-    def apply_elems(self, which, X, XG, Y, YG, alpha):
+    def apply_elems(self, which, X, XG, Y, YG, alpha, beta):
+        """beta must be the value scale() was called with (see l3k_mf_scale in include/l3k.h)."""
         nc, ldx = self._cols(X)
         _, ldy = self._cols(Y)
         ldxg = XG.shape[1] if XG is not None else 0
         ldyg = YG.shape[1] if YG is not None else 0
         check(capi.load().l3k_mf_apply_elems(self._h, which, _ptr(X), ldx, _ptr(XG), ldxg, _ptr(Y), ldy, _ptr(YG), ldyg,
-                                             nc, alpha))
+                                             nc, alpha, beta))
 
     def dirichlet_rows(self, X, Y, alpha):
         nc, ldx = self._cols(X)

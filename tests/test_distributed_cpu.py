@@ -39,7 +39,7 @@ class OracleBackend:
     def unpack_add_rows(self, src, idx, Y):
         Y[:, idx.long()] += src
 
-    def apply_elems(self, which, X, XG, Y, YG, alpha):
+    def apply_elems(self, which, X, XG, Y, YG, alpha, beta):  # beta already applied to every row by scale()
         ng = self.mesh.n_local_dofs - self.n_owned
         nc = X.shape[0]
         xg = XG[:, :ng] if XG is not None else torch.zeros((nc, ng), dtype=torch.float64)

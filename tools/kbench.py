@@ -23,12 +23,12 @@ def run_one(order, ne, steps, perturb):
     X = system.synthetic_vector_torch(part.node_grid_id, U, "cuda")
     Y = torch.zeros_like(X)
     for _ in range(3):
-        mf.apply_elems(2, X, None, Y, None, 1.0)
+        mf.apply_elems(2, X, None, Y, None, 1.0, 0.0)
     e0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     e1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     for i in range(steps):
         e0[i].record()
-        mf.apply_elems(2, X, None, Y, None, 1.0)
+        mf.apply_elems(2, X, None, Y, None, 1.0, 0.0)
         e1[i].record()
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])
