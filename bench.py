@@ -37,6 +37,18 @@ def algorithmic_bytes_per_dof(p, U, F=0):
     return 16.0 + (4.0 * npe + 192.0) / (p ** 3 * U) + 8.0 * F / U
 
 
+def measured_traffic(ne, p):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes), or None when no profile of this workload is committed."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        if t["workload"] == f"{ne}x{ne}x{ne} order {p}":
+            return t["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(p, U, seconds_target=15.0):
     """The CPU oracle (port of the reference algorithm: per-element gather, sum-factorised sweeps in the reference's
     order, atomic scatter, element loop over all host threads) timed on a bounded sample of the same workload."""
@@ -166,9 +178,11 @@ def main():
             alg_bytes = bpd * global_dofs
             achieved = alg_bytes / (ms * 1e-3) / 1e9
             result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                  "kernel": "sumfactApplyKernel", "kernel_ms": ms, "bytes_per_dof": bpd,
-                                  "dofs_per_launch": global_dofs}
+                                  "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.ne, p),
+                                  "kernel": "sumfactFastKernel", "kernel_ms": ms, "bytes_per_dof": bpd,
+                                  "dofs_per_launch": global_dofs, "algorithmic_bytes_per_launch": alg_bytes,
+                                  "fp64_note": "the kernel is FP64-VALU/LDS bound, not HBM bound (DESIGN.md): measured "
+                                               "vector FP64 peak 57.5 TFLOP/s (tools/fp64_peak.hip)"}
             if not args.no_cpu_baseline:
                 base, (spart, smask, sx, sy) = cpu_baseline(p, U)
                 result["cpu_baseline"] = base
