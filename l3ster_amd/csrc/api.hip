@@ -738,7 +738,6 @@ int l3k_unpack_add_rows(l3k_ctx* ctx, const double* d_src, int64_t n, const int3
 int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
                     size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg, int finalize)
 {
-    (void)d_diag_ghost;
     if (!mf || !d_rhs)
     {
         setError("l3k_mf_diag_rhs: null argument");
@@ -755,6 +754,11 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
     a.ldyg           = ldrg;
     a.diag           = d_diag;
     a.diag_g         = d_diag_ghost;
+    if (mf->mesh->n_ghost_nodes > 0 && which != 0 && (!d_rhs_ghost || (d_diag && !d_diag_ghost)))
+    {
+        setError("mesh has ghost nodes: border elements need the ghost diag / rhs buffers");
+        return -1;
+    }
     const auto* inst = instanceFor(mf, mf->n_rhs);
     if (!inst)
         return -4;

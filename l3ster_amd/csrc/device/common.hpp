@@ -14,6 +14,7 @@ namespace l3k::dev
 inline constexpr int max_unknowns = 8;
 
 // 1-D tables of one (p, nq) pair in HBM, layout: I[n][nq] | C[nq][nq] | qw[nq] | qx[nq] | D[n][nq] | gll[n] |
+// product tables II | ID | DD (diagonal kernel) after the
 // even-odd tables of I (n->nq), C (nq->nq), I^T (nq->n), C^T (nq->nq): for W (nin x nout) with the symmetry
 // W[nin-1-b][nout-1-q] = s*W[b][q] (s = +1 interpolation, -1 derivative) two row-major arrays
 // We, Wo of ceil(nin/2) x ceil(nout/2) each (see host/tables.cpp:evenOddTables and device/sumfact_fast.hpp:sweepEO).
@@ -32,7 +33,10 @@ struct TableLayout
     constexpr int offEoC() const { return offEoI() + 2 * hn() * hq(); }    // each hq x hq
     constexpr int offEoIt() const { return offEoC() + 2 * hq() * hq(); }   // each hq x hn
     constexpr int offEoCt() const { return offEoIt() + 2 * hq() * hn(); }  // each hq x hq
-    constexpr int size() const { return offEoCt() + 2 * hq() * hq(); }
+    constexpr int offII() const { return offEoCt() + 2 * hq() * hq(); }   // I*I, I*D, D*D elementwise, n x nq each
+    constexpr int offID() const { return offII() + n * nq; }
+    constexpr int offDD() const { return offID() + n * nq; }
+    constexpr int size() const { return offDD() + n * nq; }
 };
 
 // Everything an element kernel needs; passed by value as the kernel argument (scalar loads).

@@ -6,6 +6,7 @@
 #include "../user_kernels.hpp"
 #include "sumfact_apply.hpp"
 #include "sumfact_fast.hpp"
+#include "diag.hpp"
 
 namespace l3k::dev
 {
@@ -43,7 +44,7 @@ constexpr LaunchFn selectApply()
         {                                                                                                              \
             ::l3k::dev::registerInstance({::l3k::dev::KernelId< T >::value, P, NQ, R,                                  \
                                           ::l3k::dev::selectApply< T, P, NQ, R >(),                                  \
-                                          &::l3k::dev::launchSumfactApply< T, P, NQ, R, true >, nullptr});            \
+                                          &::l3k::dev::launchDiagRhs< T, P, NQ, R >, nullptr});                      \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
     }

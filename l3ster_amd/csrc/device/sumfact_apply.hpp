@@ -16,6 +16,8 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <utility>
+
 namespace l3k::dev
 {
 constexpr int cmax(int a, int b)
@@ -137,7 +139,7 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
 // The quadrature-point stage (evalAtHexQPs, algsys/SumFactorization.hpp:707-753) for one point.
 // v[op], dv[d][op]: values / REFERENCE derivatives of the operands (op = u + U*r) and, after them, the F fields.
 // On return r0[op], rd[d][op] hold A0^T t and D_d^T t.  RHS_MODE: t = wgt * (f - B x) (rhs with Dirichlet lifting).
-template < typename K, int R, bool RHS_MODE >
+template < typename K, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
 __device__ __forceinline__ void qpStage(const K&      kern,
                                         const double (*G)[3],
                                         double        xi,
@@ -150,7 +152,7 @@ __device__ __forceinline__ void qpStage(const K&      kern,
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations, F = params.n_fields, OPS = U * R;
-    using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, R} >;
+    using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, RT} >; // rhs is E x RT, columns C0..C0+R-1 used
 
     double Jm[3][3], Ji[3][3], xyz[3];
     hexPointOnPencil(G, xi, Jm, xyz);
@@ -192,7 +194,7 @@ __device__ __forceinline__ void qpStage(const K&      kern,
             for (int u = 0; u < U; ++u)
                 acc += res.operators[0](e, u) * v[r * U + u] + Dm[0][e][u] * dv[0][r * U + u] +
                        Dm[1][e][u] * dv[1][r * U + u] + Dm[2][e][u] * dv[2][r * U + u];
-            t[e] = RHS_MODE ? wgt * (res.rhs(e, r) - acc) : wgt * acc;
+            t[e] = RHS_MODE ? wgt * (res.rhs(e, C0 + r) - acc) : wgt * acc;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -233,7 +235,7 @@ constexpr size_t applyLdsBytes()
 // RHS_MODE == true : rhs += B^T W (f - B g)   with g = Dirichlet values on Dirichlet dofs, 0 elsewhere
 //                    (precomputeDiagRhsImpl's rhs, algsys/EvaluateLocalOperator.hpp:187,195-207, in sum-factorised
 //                    form; nothing is skipped in the scatter, as scatterInit :377-390)
-template < typename K, int P, int NQ, int R, bool RHS_MODE >
+template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
 __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(const ElemArgs a, const K kern)
 {
     constexpr KernelParams params = K::params;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         const double* qp = a.tables + TL.offX();
         double G[6][3];
         hexPencilGeom(vs, qp[qy], qp[qz], G);
-        qpStage< K, R, RHS_MODE >(kern, G, qp[qx], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd);
+        qpStage< K, R, RHS_MODE, RT, C0 >(kern, G, qp[qx], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd);
 #pragma unroll
         for (int o = 0; o < OPS; ++o)
         {
@@ -386,27 +388,40 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
 
 inline constexpr size_t lds_limit_bytes = 160 * 1024; // LDS per CU on gfx950; one workgroup may use all of it
 
-template < typename K, int P, int NQ, int R, bool RHS_MODE >
+template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
+int launchSumfactApply(const ElemArgs& a, const void* kparam_blob, hipStream_t stream);
+
+// column C of an RT-column operand with the single-column kernel, then the remaining columns
+template < typename K, int P, int NQ, bool RHS_MODE, int RT, int C >
+int launchColumns(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    if constexpr (C < RT)
+    {
+        ElemArgs c       = a;
+        c.x              = a.x ? a.x + a.ldx * C : nullptr;
+        c.xg             = a.xg ? a.xg + a.ldxg * C : nullptr;
+        c.y              = a.y ? a.y + a.ldy * C : nullptr;
+        c.yg             = a.yg ? a.yg + a.ldyg * C : nullptr;
+        c.dirichlet_vals = a.dirichlet_vals ? a.dirichlet_vals + a.ldg * C : nullptr;
+        if (int rc = launchSumfactApply< K, P, NQ, 1, RHS_MODE, RT, C >(c, kparam_blob, stream))
+            return rc;
+        return launchColumns< K, P, NQ, RHS_MODE, RT, C + 1 >(a, kparam_blob, stream);
+    }
+    else
+        return 0;
+}
+
+template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT, int C0 >
 int launchSumfactApply(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
 {
     if (a.elem_count <= 0)
         return 0;
     if constexpr (applyLdsBytes< K, P, NQ, R >() > lds_limit_bytes && R > 1)
     {
-        // the R-column working set does not fit the LDS: run column by column with the R = 1 instantiation, as the
-        // reference does when fewer columns than n_rhs are passed (algsys/MatrixFreeSystem.hpp:1124-1138)
-        for (int r = 0; r < R; ++r)
-        {
-            ElemArgs c = a;
-            c.x        = a.x ? a.x + a.ldx * r : nullptr;
-            c.xg       = a.xg ? a.xg + a.ldxg * r : nullptr;
-            c.y        = a.y ? a.y + a.ldy * r : nullptr;
-            c.yg       = a.yg ? a.yg + a.ldyg * r : nullptr;
-            c.dirichlet_vals = a.dirichlet_vals ? a.dirichlet_vals + a.ldg * r : nullptr;
-            if (int rc = launchSumfactApply< K, P, NQ, 1, RHS_MODE >(c, kparam_blob, stream))
-                return rc;
-        }
-        return 0;
+        // the R-column working set does not fit the LDS: run column by column with the single-column kernel, as the
+        // reference does when fewer columns than n_rhs are passed (algsys/MatrixFreeSystem.hpp:1124-1138); the user
+        // kernel still sees an E x R rhs and column c of it is used
+        return launchColumns< K, P, NQ, RHS_MODE, R, 0 >(a, kparam_blob, stream);
     }
     else
     {
@@ -415,7 +430,7 @@ int launchSumfactApply(const ElemArgs& a, const void* kparam_blob, hipStream_t s
         if (kparam_blob)
             __builtin_memcpy(&kern, kparam_blob, sizeof(K));
         constexpr size_t lds      = applyLdsBytes< K, P, NQ, R >();
-        auto             kernel   = sumfactApplyKernel< K, P, NQ, R, RHS_MODE >;
+        auto             kernel   = sumfactApplyKernel< K, P, NQ, R, RHS_MODE, RT, C0 >;
         static bool      attr_set = false;
         if (!attr_set)
         {

@@ -205,6 +205,10 @@ std::vector< double > deviceTableBlock(int p, int nq)
     append(C, nq, nq, true);
     append(It, nq, n, false);
     append(Ct, nq, nq, true);
+    // elementwise product tables for the sum-factorised diagonal (device/diag.hpp)
+    for (int which = 0; which < 3; ++which)
+        for (size_t i = 0; i < I.size(); ++i)
+            out.push_back(which == 0 ? I[i] * I[i] : (which == 1 ? I[i] * D[i] : D[i] * D[i]));
     return out;
 }
 } // namespace l3k::host

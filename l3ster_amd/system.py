@@ -287,6 +287,27 @@ class MatrixFreeSystem:
         nc, ld = self._cols(dst)
         check(capi.load().l3k_unpack_add_rows(self.ctx._h, _ptr(src), idx.numel(), _ptr(idx), _ptr(dst), ld, nc))
 
+    def diag_rhs(self, dirichlet_vals=None, which=2, diag=None, rhs=None, diag_ghost=None, rhs_ghost=None,
+                 finalize=True):
+        """computeDiagAndRhs (algsys/MatrixFreeSystem.hpp:888-941): diag(A) and the rhs with Dirichlet lifting.
+        dirichlet_vals: (n_rhs, n_local_dofs) tensor or None (= 0).  Returns (diag [n_owned], rhs (n_rhs, n_owned));
+        accumulates into the given tensors (the caller zeroes them), allocates zeroed ones otherwise."""
+        import torch
+        n_owned, n_ghost = self.mesh.n_owned_dofs, self.mesh.n_ghost_dofs
+        dev = "cuda"
+        if diag is None:
+            diag = torch.zeros(n_owned, dtype=torch.float64, device=dev)
+        if rhs is None:
+            rhs = torch.zeros((self.n_rhs, n_owned), dtype=torch.float64, device=dev)
+        if n_ghost and diag_ghost is None:
+            diag_ghost = torch.zeros(n_ghost, dtype=torch.float64, device=dev)
+            rhs_ghost = torch.zeros((self.n_rhs, n_ghost), dtype=torch.float64, device=dev)
+        g = dirichlet_vals
+        ldg = 0 if g is None else g.shape[1]
+        check(capi.load().l3k_mf_diag_rhs(self._h, which, _ptr(g), ldg, _ptr(diag), _ptr(rhs), rhs.shape[1],
+                                          _ptr(diag_ghost), _ptr(rhs_ghost), max(n_ghost, 1), int(finalize)))
+        return diag, rhs
+
     def new_ghost_buffer(self, ncols, like):
         import torch
         return torch.zeros((ncols, max(self.mesh.n_ghost_dofs, 1)), dtype=torch.float64, device=like.device)

@@ -157,3 +157,40 @@ def test_operator_properties_at_scale(ctx, ne, p):
     om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
     y_ref = O.mf_apply(om, 0, x.cpu().numpy().T, nthreads=8)
     assert rel_err(Ax.cpu().numpy().T, y_ref) < 1e-11
+
+
+DIAG_CASES = [
+    # kid, ne, p, value_order, n_rhs
+    (system.KERNEL_DIFFUSION3D, 3, 2, 1, 1),
+    (system.KERNEL_DIFFUSION3D, 2, 3, 2, 3),
+    (system.KERNEL_DIFFUSION3D, 2, 6, 1, 1),
+    (system.KERNEL_DIFFUSION3D_VAR, 2, 3, 2, 2),
+    (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1),
+    (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2),
+]
+
+
+@pytest.mark.parametrize("kid,ne,p,vo,R", DIAG_CASES)
+def test_diag_and_lifted_rhs_vs_oracle(ctx, kid, ne, p, vo, R):
+    """computeDiagAndRhs (algsys/MatrixFreeSystem.hpp:888-941): diag(A) (needed by the Jacobi preconditioner,
+    solve/NativePreconditioners.hpp:36-96) and rhs = sum_e B^T W f - A[:, D] g_D with rhs[D] = g_D, diag[D] = 1."""
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(ne, p, perturb=0.1)
+    nq = system.n_qps1d(p, vo)
+    mask = part.dirichlet_mask(U)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    kpar = {0: [0.7, 1.3], 4: [0.7, 1.3, 0.5]}.get(kid)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar, asm_opts=(vo, 0, 0), n_rhs=R)
+    fields = random_fields(part, F, 5) if F else None
+    if F:
+        mf.set_fields(dev(fields))
+    n = part.n_local_nodes * U
+    g = np.random.default_rng(6).uniform(-1, 1, (R, n)) * mask[None, :]
+    diag, rhs = mf.diag_rhs(dev(g))
+    torch.cuda.synchronize()
+    om = oracle_mesh(part, nq, U, np.arange(U), mask, fields)
+    d_ref, r_ref = O.mf_diag_rhs(om, kid, R, np.asfortranarray(g.T), kparams=kpar)
+    assert rel_err(diag.cpu().numpy(), d_ref) < 1e-11
+    assert rel_err(rhs.cpu().numpy().T, r_ref) < 1e-11
+    assert np.all(diag.cpu().numpy()[mask.astype(bool)] == 1.0)
