@@ -162,6 +162,13 @@ struct l3k_mf
     size_t              ldf    = 0;
     double              time   = 0.;
     bool                dense = false, fuse = false;
+    double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
+    size_t              ws_doubles = 0;
+    ~l3k_mf()
+    {
+        if (ws)
+            (void)hipFree(ws);
+    }
 };
 
 namespace
@@ -776,8 +783,72 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
 
 int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum)
 {
-    (void)mf, (void)first, (void)count, (void)d_K, (void)d_F, (void)d_checksum;
-    setError("l3k_local_assemble: not built yet in this round");
-    return -5;
+    if (!mf)
+    {
+        setError("null mf");
+        return -1;
+    }
+    const l3k_mesh* m = mf->mesh;
+    if (first < 0 || count < 0 || first + count > m->n_elems)
+    {
+        setError("element range [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)m->n_elems);
+        return -1;
+    }
+    if (count == 0)
+        return 0;
+    const auto* inst = instanceFor(mf, mf->n_rhs);
+    if (!inst)
+        return -4;
+    l3k::dev::ElemArgs a;
+    if (int rc = fillArgs(mf, 2, mf->n_rhs, a))
+        return rc;
+    a.elem_begin     = first;
+    a.elem_count     = count;
+    a.elem_begin_out = 0;
+    a.K              = d_K;
+    a.F              = d_F;
+    a.checksum       = d_checksum;
+    hipStream_t s    = mf->ctx->stream;
+    const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
+    if (d_K || d_checksum)
+    {
+        const size_t need = inst->assemble_ws_doubles * size_t(count) + 1;
+        if (need > mf->ws_doubles)
+        {
+            if (mf->ws)
+                L3K_HIP(hipFree(mf->ws));
+            mf->ws = nullptr;
+            L3K_HIP(hipMalloc(reinterpret_cast< void** >(&mf->ws), need * sizeof(double)));
+            mf->ws_doubles = need;
+        }
+        a.workspace = mf->ws;
+        double* flag = mf->ws + inst->assemble_ws_doubles * size_t(count);
+        L3K_HIP(hipMemsetAsync(flag, 0, sizeof(double), s));
+        if (d_checksum)
+            L3K_HIP(hipMemsetAsync(d_checksum, 0, sizeof(double) * size_t(count), s));
+        if (int rc = inst->assemble(a, blob, s))
+            return rc;
+        double degenerate = 0.;
+        L3K_HIP(hipMemcpyAsync(&degenerate, flag, sizeof(double), hipMemcpyDeviceToHost, s));
+        L3K_HIP(hipStreamSynchronize(s));
+        if (degenerate != 0.)
+        {
+            setError("Encountered degenerate element ( |J| <= 0 )"); // algsys/AssembleLocalSystem.hpp:249
+            return -2;
+        }
+    }
+    if (d_F)
+    {
+        // F_e = sum_q w detJ B_q^T f_q: the sum-factorised RHS-mode kernel without Dirichlet lifting, element-local output
+        a.dirichlet      = nullptr;
+        a.elem_flags     = nullptr;
+        a.dirichlet_vals = nullptr;
+        a.diag           = nullptr;
+        a.local_out      = 1;
+        a.y              = d_F; // unused for addressing in local_out mode, must be non-null
+        if (int rc = inst->diag_rhs(a, blob, s))
+            return rc;
+    }
+    return 0;
 }
 } // extern "C"

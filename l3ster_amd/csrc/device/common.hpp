@@ -68,9 +68,12 @@ struct ElemArgs
     double*       diag;
     double*       diag_g;
     // local assembly
-    double* K;
-    double* F;
-    double* checksum;
+    double* K;         // [count][Nd][Nd] row-major or nullptr
+    double* F;         // [count][Nd][R] column-major per element (RHS-mode kernel with local_out)
+    double* checksum;  // [count] or nullptr
+    double* workspace; // per-QP coefficients of the batch + 1 trailing flag (degenerate element)
+    int64_t elem_begin_out; // output slot of the first element of the batch
+    int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS); 0 in production
 };
@@ -83,6 +86,7 @@ struct Instance
     LaunchFn apply;
     LaunchFn diag_rhs;
     LaunchFn assemble;
+    size_t   assemble_ws_doubles; // workspace doubles per element for `assemble`
 };
 
 void            registerInstance(const Instance& inst);

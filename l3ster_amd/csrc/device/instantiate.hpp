@@ -7,6 +7,7 @@
 #include "sumfact_apply.hpp"
 #include "sumfact_fast.hpp"
 #include "diag.hpp"
+#include "assemble.hpp"
 
 namespace l3k::dev
 {
@@ -44,7 +45,9 @@ constexpr LaunchFn selectApply()
         {                                                                                                              \
             ::l3k::dev::registerInstance({::l3k::dev::KernelId< T >::value, P, NQ, R,                                  \
                                           ::l3k::dev::selectApply< T, P, NQ, R >(),                                  \
-                                          &::l3k::dev::launchDiagRhs< T, P, NQ, R >, nullptr});                      \
+                                          &::l3k::dev::launchDiagRhs< T, P, NQ, R >,                               \
+                                          &::l3k::dev::launchAssemble< T, P, NQ >,                                 \
+                                          ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >()});             \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
     }

@@ -368,6 +368,12 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         {
             const double val = (RHS_MODE ? 1. : a.alpha) * B0[(r * U + u) * M3 + i];
             double* dst = dof < a.n_owned_dofs ? a.y + dof + a.ldy * r : a.yg + (dof - a.n_owned_dofs) + a.ldyg * r;
+            if constexpr (RHS_MODE)
+                if (a.local_out) // F_e of assembleLocalSystem: column-major [Nd][RT] per element, written once
+                {
+                    a.F[((e - a.elem_begin) + a.elem_begin_out) * int64_t(NN * U) * RT + (i * U + u) + int64_t(NN * U) * (C0 + r)] = val;
+                    continue;
+                }
             if (a.dbg & 1)
             {
                 if (val == 1.2345e300)

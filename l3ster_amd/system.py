@@ -173,7 +173,7 @@ class Context:
         check(capi.load().l3k_ctx_synchronize(self._h))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and capi is not None:  # (module globals may be gone at interpreter shutdown)
             capi.load().l3k_ctx_destroy(self._h)
             self._h = None
 
@@ -201,7 +201,7 @@ class DeviceMesh:
         self.n_ghost_dofs = part.n_ghost_nodes * dofs_per_node
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and capi is not None:
             capi.load().l3k_mesh_destroy(self._h)
             self._h = None
 
@@ -232,7 +232,7 @@ class MatrixFreeSystem:
         self._fields = None
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and capi is not None:
             capi.load().l3k_mf_destroy(self._h)
             self._h = None
 
@@ -307,6 +307,18 @@ class MatrixFreeSystem:
         check(capi.load().l3k_mf_diag_rhs(self._h, which, _ptr(g), ldg, _ptr(diag), _ptr(rhs), rhs.shape[1],
                                           _ptr(diag_ghost), _ptr(rhs_ghost), max(n_ghost, 1), int(finalize)))
         return diag, rhs
+
+    def local_assemble(self, first=0, count=None, want_K=True, want_F=True, want_checksum=False):
+        """assembleLocalSystem for elements [first, first+count) (algsys/AssembleLocalSystem.hpp:234-256).
+        Returns (K [count, Nd, Nd] row-major, F [count, n_rhs, Nd] i.e. column-major Nd x n_rhs per element, checksum)."""
+        import torch
+        count = self.mesh.part.n_elems - first if count is None else count
+        Nd = (self.mesh.part.order + 1) ** 3 * self.info["n_unknowns"]
+        K = torch.empty((count, Nd, Nd), dtype=torch.float64, device="cuda") if want_K else None
+        F = torch.zeros((count, self.n_rhs, Nd), dtype=torch.float64, device="cuda") if want_F else None
+        cs = torch.empty(count, dtype=torch.float64, device="cuda") if want_checksum else None
+        check(capi.load().l3k_local_assemble(self._h, first, count, _ptr(K), _ptr(F), _ptr(cs)))
+        return K, F, cs
 
     def new_ghost_buffer(self, ncols, like):
         import torch

@@ -1,0 +1,91 @@
+"""GPU parity tests of LocalAssembly (K_e via FP64 MFMA, F_e): HIP path through the C ABI vs the oracle's
+assembleLocalSystem restatement and the golden fixtures.  Tolerance: max-norm 1e-12 relative to |K_e|_max (stated fp64
+tolerance)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from helpers import HEX, SingleElementMesh
+from l3ster_amd import system
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return system.Context(0, torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+def checksum_of(K):
+    n = K.shape[0]
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    return float((K * (1 + (i * 31 + j * 17) % 7)).sum())
+
+
+CASES = [
+    # kid, ne, p, value_order, R, kparams
+    (system.KERNEL_DIFFUSION3D, 2, 1, 1, 1, [0.7, 1.3]),
+    (system.KERNEL_DIFFUSION3D, 2, 2, 1, 2, [0.7, 1.3]),
+    (system.KERNEL_DIFFUSION3D, (2, 1, 1), 3, 2, 3, [1.0, 0.5]),
+    (system.KERNEL_DIFFUSION3D_VAR, (2, 1, 1), 3, 2, 2, None),
+    (system.KERNEL_ADVDIFF3D, 2, 2, 1, 2, [0.7, 1.3, 0.5]),
+    (system.KERNEL_DIFFUSION3D, (2, 1, 1), 4, 1, 1, [1.0, 1.0]),
+]
+
+
+@pytest.mark.parametrize("kid,ne,p,vo,R,kpar", CASES)
+def test_local_assembly_vs_oracle(ctx, kid, ne, p, vo, R, kpar):
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(ne, p, perturb=0.15)
+    nq = system.n_qps1d(p, vo)
+    mesh = system.DeviceMesh(ctx, part, U)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar, asm_opts=(vo, 0, 0), n_rhs=R)
+    fields = np.random.default_rng(2).uniform(-1, 1, (F, part.n_local_nodes)) if F else None
+    if F:
+        mf.set_fields(dev(fields))
+    K, Fe, cs = mf.local_assemble(want_checksum=True)
+    torch.cuda.synchronize()
+    K, Fe, cs = K.cpu().numpy(), Fe.cpu().numpy(), cs.cpu().numpy()
+    for e in range(part.n_elems):
+        nf = fields[:, part.elem_nodes[e]].T if F else None
+        K_ref, F_ref = O.assemble_local(kid, p, nq, R, part.elem_verts[e], nf, kpar)
+        scale = np.abs(K_ref).max()
+        assert np.abs(K[e] - K_ref).max() < 1e-12 * scale
+        assert np.abs(Fe[e].T - F_ref).max() < 1e-12 * max(1.0, np.abs(F_ref).max())
+        assert np.array_equal(K[e], K[e].T)  # mirrored from the lower triangle (AssembleLocalSystem.hpp:176-182)
+        assert abs(cs[e] - checksum_of(K[e])) < 1e-9 * abs(checksum_of(np.abs(K[e])))
+
+
+def test_local_assembly_order6_vs_golden(ctx, golden):
+    """The north-star shape (order 6, 1372 x 1372) on the reference's distorted test hex: K x, diag(K), F vs the
+    independent numpy/mpmath restatement; checksum-only (streaming) mode gives the same checksum."""
+    g = golden("hex_p6_diff")
+    mesh = system.DeviceMesh(ctx, SingleElementMesh(6, g["verts"]), 4)
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, g["kparams"])
+    K, Fe, cs = mf.local_assemble(want_checksum=True)
+    _, _, cs2 = mf.local_assemble(want_K=False, want_F=False, want_checksum=True)
+    torch.cuda.synchronize()
+    K = K.cpu().numpy()[0]
+    assert np.linalg.norm(K @ g["x"] - g["y"]) < 1e-12 * np.linalg.norm(g["y"])
+    np.testing.assert_allclose(np.diag(K), g["diag"], rtol=1e-12)
+    np.testing.assert_allclose(Fe.cpu().numpy()[0].T, g["F"], atol=1e-13)
+    assert np.array_equal(K, K.T) and np.linalg.eigvalsh(K).min() > -1e-10
+    assert abs(cs.item() - cs2.item()) <= 1e-12 * abs(cs.item())
+    assert abs(cs.item() - checksum_of(K)) < 1e-9 * checksum_of(np.abs(K))
+
+
+def test_degenerate_element_is_an_error(ctx):
+    bad = HEX.copy()
+    bad[[0, 1]] = bad[[1, 0]]
+    mesh = system.DeviceMesh(ctx, SingleElementMesh(2, bad), 4)
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D)
+    with pytest.raises(system.L3KError, match="degenerate"):
+        mf.local_assemble()
