@@ -1,0 +1,94 @@
+"""Jacobi-PCG driven by the matrix-free operator.  CPU: l3ster_amd.solve on top of the oracle's apply (pins solve.py and
+the 3-D analogue of the reference's end-to-end diffusion test, tests/Diffusion2D.hpp:17-121: Dirichlet T = x, zero
+source, exact solution T = x, q = (1,0,0), error < 1e-8).  GPU: the same through the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from helpers import oracle_mesh
+from l3ster_amd import solve, system
+
+
+def node_coords(part):
+    gll = system.gll_nodes(part.order + 1)
+    n = part.order + 1
+    xyz = np.zeros((part.n_local_nodes, 3))
+    for e in range(part.n_elems):
+        for i in range(n ** 3):
+            xyz[part.elem_nodes[e, i]] = O.map_to_physical(3, part.elem_verts[e], [gll[i % n], gll[(i // n) % n], gll[i // (n * n)]])
+    return xyz
+
+
+def setup_problem(ne, p):
+    U = 4
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    xyz = node_coords(part)
+    g = np.zeros((part.n_local_nodes, U))
+    g[:, 0] = xyz[:, 0]  # T = x on the boundary (only the masked entries matter)
+    g = (g.reshape(-1) * mask)[None, :]
+    exact = np.zeros((part.n_local_nodes, U))
+    exact[:, 0], exact[:, 1] = xyz[:, 0], 1.0
+    return part, mask, g, exact.reshape(-1)
+
+
+def test_pcg_with_oracle_operator_reproduces_linear_solution():
+    p, kpar = 2, [1.0, 0.0]
+    part, mask, g, exact = setup_problem(3, p)
+    om = oracle_mesh(part, p + 1, 4, np.arange(4), mask)
+    diag, rhs = O.mf_diag_rhs(om, 0, 1, np.asfortranarray(g.T), kparams=kpar)
+    minv = solve.jacobi_inverse(torch.as_tensor(diag))
+
+    def apply(v, out):
+        out.copy_(torch.as_tensor(O.mf_apply(om, 0, v.numpy().reshape(-1, 1), kparams=kpar)[:, 0]))
+
+    x = torch.zeros(len(diag), dtype=torch.float64)
+    res = solve.cg(apply, torch.as_tensor(rhs[:, 0].copy()), x, minv, tol=1e-11, residual_scaling="rhs")
+    assert res.converged and res.num_iters < 400
+    assert np.abs(x.numpy() - exact).max() < 1e-8
+    # Jacobi: sign(d)*damping/max(|d|, threshold), solve/NativePreconditioners.hpp:75-96
+    d = torch.tensor([2.0, -4.0, 1e-9])
+    assert torch.allclose(solve.jacobi_inverse(d, 0.5, 1e-3), torch.tensor([0.25, -0.125, 500.0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kid,ne,p", [(system.KERNEL_DIFFUSION3D, 3, 2), (system.KERNEL_DIFFUSION3D, 2, 4),
+                                      (system.KERNEL_ADVDIFF3D, 3, 2)])
+def test_gpu_pcg_matches_cpu_restatement(kid, ne, p):
+    """Config-5 style solve: iterations to tolerance equal (+-1) to the CPU restatement, same solution; for the pure
+    diffusion kernel the exact linear solution is reproduced (< 1e-8)."""
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part, mask, g, exact = setup_problem(ne, p)
+    kpar = [1.0, 0.0] if kid == system.KERNEL_DIFFUSION3D else [1.0, 0.3, 0.0]
+    fields = None
+    if F:  # smooth analytic velocity
+        xyz = node_coords(part)
+        fields = np.stack([0.2 * np.sin(np.pi * xyz[:, 1]), 0.1 * np.cos(np.pi * xyz[:, 0]), 0.05 * xyz[:, 2]])
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar)
+    if F:
+        mf.set_fields(torch.as_tensor(fields, device="cuda"))
+    G = torch.as_tensor(g, device="cuda")
+    diag, rhs = mf.diag_rhs(G)
+    minv = solve.jacobi_inverse(diag)
+    x = torch.zeros_like(diag)
+    res = solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x, minv, tol=1e-10, residual_scaling="rhs")
+    # CPU restatement of the same solve
+    om = oracle_mesh(part, p + 1, U, np.arange(U), mask, fields)
+    d_ref, r_ref = O.mf_diag_rhs(om, kid, 1, np.asfortranarray(g.T), kparams=kpar)
+
+    def apply_cpu(v, out):
+        out.copy_(torch.as_tensor(O.mf_apply(om, kid, v.numpy().reshape(-1, 1), kparams=kpar)[:, 0]))
+
+    x_ref = torch.zeros(len(d_ref), dtype=torch.float64)
+    res_ref = solve.cg(apply_cpu, torch.as_tensor(r_ref[:, 0].copy()), x_ref, solve.jacobi_inverse(torch.as_tensor(d_ref)),
+                       tol=1e-10, residual_scaling="rhs")
+    assert abs(res.num_iters - res_ref.num_iters) <= 1
+    assert np.linalg.norm(x.cpu().numpy() - x_ref.numpy()) < 1e-7 * np.linalg.norm(x_ref.numpy())
+    if kid == system.KERNEL_DIFFUSION3D:
+        assert np.abs(x.cpu().numpy() - exact).max() < 1e-7
