@@ -105,8 +105,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("L3K_FORCE_DIST") == "1"  # the latter: smoke-test of the N > 1 code path at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     p, U, kid = args.order, 4, system.KERNEL_DIFFUSION3D
@@ -122,7 +124,7 @@ def main():
     n_owned = part.n_owned_nodes * U
     X = system.synthetic_vector_torch(part.node_grid_id[:part.n_owned_nodes], U, dev)
     Y = torch.empty_like(X)
-    op = DistributedOperator(mf, HaloPlan(part, U, dev)) if world > 1 else None
+    op = DistributedOperator(mf, HaloPlan(part, U, dev)) if use_dist else None
     t_setup = time.perf_counter() - t_setup
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -142,7 +144,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +156,7 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -173,7 +175,7 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "setup_s": round(t_setup, 2)},
     }
     if rank == 0:
-        if world == 1:
+        if world == 1 and op is None:
             ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
             alg_bytes = bpd * global_dofs
             achieved = alg_bytes / (ms * 1e-3) / 1e9
@@ -198,7 +200,7 @@ def main():
                 if not err < 1e-11:
                     raise SystemExit(f"GPU result differs from the oracle: rel L2 {err}")
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

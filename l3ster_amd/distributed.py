@@ -39,9 +39,28 @@ class HaloPlan:
                 self.owners.append((nb, g0 * dpn, g1 * dpn))
 
 
+class TorchDistTransport:
+    """Neighbour exchange over torch.distributed point-to-point ops (RCCL on GPUs, gloo on CPU): every message of one
+    phase is posted in a single batch_isend_irecv (one ncclGroupStart/End)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def post(self, sends, recvs):
+        ops = [dist.P2POp(dist.isend, t, peer, self.group) for peer, t in sends]
+        ops += [dist.P2POp(dist.irecv, t, peer, self.group) for peer, t in recvs]
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def wait(reqs):
+        for r in reqs:
+            r.wait()
+
+
 class DistributedOperator:
-    def __init__(self, backend, plan, group=None):
-        self.backend, self.plan, self.group = backend, plan, group
+    def __init__(self, backend, plan, group=None, transport=None):
+        self.backend, self.plan = backend, plan
+        self.transport = transport or TorchDistTransport(group)
         self._bufs = {}
 
     def _buffers(self, ncols, like):
@@ -63,37 +82,31 @@ class DistributedOperator:
         be.scale(Y, beta)
         yg.zero_()
         # ---- import: owner -> sharer
-        ops = []
+        sends, recvs = [], []
         for (nb, idx), sbuf in zip(plan.sharers, b["send"]):
             be.pack_rows(X, idx, sbuf)
-            ops.append(dist.P2POp(dist.isend, sbuf, nb, self.group))
-        recv_targets = []
+            sends.append((nb, sbuf))
         for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
-            tgt = xg[:, g0:g1] if nc == 1 else stage  # one column: receive straight into the ghost slab
-            recv_targets.append(tgt)
-            ops.append(dist.P2POp(dist.irecv, tgt, nb, self.group))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
+            recvs.append((nb, xg[:, g0:g1] if nc == 1 else stage))  # one column: straight into the ghost slab
+        reqs = self.transport.post(sends, recvs)
         be.apply_elems(0, X, None, Y, None, alpha, beta)  # interior: overlaps the exchange
-        for r in reqs:
-            r.wait()
+        self.transport.wait(reqs)
         if nc > 1:
             for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
                 xg[:, g0:g1].copy_(stage)
         # ---- border elements, then export: sharer -> owner
         be.apply_elems(1, X, xg, Y, yg, alpha, beta)
-        ops = []
+        sends, recvs = [], []
         for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
             if nc == 1:
                 src = yg[:, g0:g1]
             else:
                 stage.copy_(yg[:, g0:g1])
                 src = stage
-            ops.append(dist.P2POp(dist.isend, src, nb, self.group))
+            sends.append((nb, src))
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
-            ops.append(dist.P2POp(dist.irecv, rbuf, nb, self.group))
-        reqs = dist.batch_isend_irecv(ops) if ops else []
-        for r in reqs:
-            r.wait()
+            recvs.append((nb, rbuf))
+        self.transport.wait(self.transport.post(sends, recvs))
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             be.unpack_add_rows(rbuf, idx, Y)
         be.dirichlet_rows(X, Y, alpha)
