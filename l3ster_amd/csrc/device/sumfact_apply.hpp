@@ -123,7 +123,11 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
     const double c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2];
     const double c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
     const double det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
-    const double id  = 1. / det;
+    // 1/det: hardware reciprocal seed + two Newton steps (quadratic convergence from ~2^-26 to < 1 ulp-ish), ~6
+    // instructions instead of the ~20 of the IEEE-exact division expansion
+    double id = __builtin_amdgcn_rcp(det);
+    id        = id * (2. - det * id);
+    id        = id * (2. - det * id);
     Mi[0][0]         = c00 * id;
     Mi[1][0]         = c01 * id;
     Mi[2][0]         = c02 * id;

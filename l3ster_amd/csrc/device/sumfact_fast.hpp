@@ -119,7 +119,7 @@ struct FastCfg
     static constexpr int    BUF_D    = 2 * NG * OS;
     static constexpr int    TEAM_D   = 2 * BUF_D + 24;
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D;
-    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUF_D;
+    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUF_D && U % 2 == 0;
 };
 
 #ifndef L3K_FAST_MIN_WAVES
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
     double        xn[N1][U];
     double        fn[N1][F > 0 ? F : 1];
     uint32_t      dm_nxt[N1];
-    const int64_t n_owned_nodes = a.n_owned_dofs / a.dofs_per_node;
+    const int64_t n_owned_nodes = a.n_owned_dofs / U;
     auto          elemOf = [&](int64_t batch) { return a.elem_begin + batch * EW + team; };
     auto valid   = [&](int64_t batch) { return batch < n_batches && on_nn && (batch * EW + team) < a.elem_count; };
     auto loadIds = [&](int64_t batch, uint32_t (&ids)[N1]) {
@@ -185,66 +185,46 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         if (!valid(batch))
             return;
         const bool flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[elemOf(batch)] != 0;
-        if constexpr (U % 2 == 0)
-            if (a.dense)
-            {
-                // node-interleaved dofs with the kernel's unknowns = all dofs of a node: 16-byte vector loads, adjacent
-                // lanes read adjacent nodes (dofs/NodeToDofMap.hpp:250-264 layout)
-#pragma unroll
-                for (int k = 0; k < N1; ++k)
-                {
-                    const int64_t node = ids[k];
-                    const double* p    = node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
-#pragma unroll
-                    for (int hh = 0; hh < U / 2; ++hh)
-                    {
-                        const double2 t = (a.dbg & 2) ? make_double2(1e-9 * double(node), 1e-9)
-                                                      : *reinterpret_cast< const double2* >(p + 2 * hh);
-                        xn[k][2 * hh]     = t.x;
-                        xn[k][2 * hh + 1] = t.y;
-                    }
-                    uint32_t dm = 0;
-                    if (flagged)
-                    {
-#pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            dm |= uint32_t(a.dirichlet[node * U + u] != 0) << u;
-                    }
-                    dm_nxt[k] = dm;
-#pragma unroll
-                    for (int f = 0; f < F; ++f)
-                        fn[k][f] = a.fields[node + f * a.ldf];
-                }
-                return;
-            }
+        // node-interleaved dofs with the kernel's unknowns = all dofs of a node (the launcher sends every other layout
+        // to the generic kernel): 16-byte vector loads, adjacent lanes read adjacent nodes
+        // (dofs/NodeToDofMap.hpp:250-264 layout)
 #pragma unroll
         for (int k = 0; k < N1; ++k)
         {
-            const int64_t nbase = int64_t(ids[k]) * a.dofs_per_node;
-            uint32_t      dm    = 0;
+            const int64_t node = ids[k];
+            const double* p    = node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int hh = 0; hh < U / 2; ++hh)
             {
-                const int64_t dof = nbase + a.field_inds[u];
-                xn[k][u] = (a.dbg & 2) ? double(dof) * 1e-9 : (dof < a.n_owned_dofs ? a.x[dof] : a.xg[dof - a.n_owned_dofs]);
-                if (flagged)
-                    dm |= uint32_t(a.dirichlet[dof] != 0) << u;
+                const double2 t = (a.dbg & 2) ? make_double2(1e-9 * double(node), 1e-9)
+                                              : *reinterpret_cast< const double2* >(p + 2 * hh);
+                xn[k][2 * hh]     = t.x;
+                xn[k][2 * hh + 1] = t.y;
+            }
+            uint32_t dm = 0;
+            if (flagged)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    dm |= uint32_t(a.dirichlet[node * U + u] != 0) << u;
             }
             dm_nxt[k] = dm;
 #pragma unroll
             for (int f = 0; f < F; ++f)
-                fn[k][f] = a.fields[ids[k] + f * a.ldf];
+                fn[k][f] = a.fields[node + f * a.ldf];
         }
     };
 
     int64_t batch = blockIdx.x;
     loadIds(batch, ids_cur);
-    loadIds(batch + gridDim.x, ids_nxt);
-    loadX(batch, ids_cur);
 
     for (; batch < n_batches; batch += gridDim.x)
     {
         const bool act = (batch * EW + team) < a.elem_count; // this team has an element in this batch
+        // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
+        // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
+        // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
+        loadX(batch, ids_cur);
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
         double u0[N1][2 * NG];
         if (on_nn && act)
@@ -265,12 +245,6 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         if (act)
             for (int t = l; t < 24; t += TEAM)
                 vs[t] = a.elem_verts[elemOf(batch) * 24 + t];
-        // rotate the id pipeline; the next batch's ids are already here, its x values are requested further down (once
-        // the quadrature-point registers are dead) and stay in flight behind the tail of this batch
-#pragma unroll
-        for (int k = 0; k < N1; ++k)
-            ids_cur[k] = ids_nxt[k];
-        loadIds(batch + 2 * int64_t(gridDim.x), ids_nxt);
 
         // ---- S1: z interpolation in registers; write (c=i, b=j, a=qz) into bufA
         if (on_nn && act)
@@ -528,7 +502,6 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             }
         }
         stageFence();
-        loadX(batch + gridDim.x, ids_cur); // prefetch: consumed at the top of the next iteration
         // ---- I^T along y, lane (ix, qz) = (iq, kq): bufB (c=ix, b=qy, a=qz) -> bufA (c=ix, b=iy, a=qz)
         if (on_nq && act)
         {
@@ -586,6 +559,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             }
         }
         stageFence();
+        loadIds(batch + gridDim.x, ids_nxt); // next element's node ids: in flight behind the scatter
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
         // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
         if (act)
@@ -599,7 +573,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                 const int     nl   = t / U;
                 const int     o    = t - nl * U;
                 const int64_t node = en[nl];
-                const int64_t dof  = node * a.dofs_per_node + a.field_inds[o];
+                const int64_t dof  = node * U + o;
                 const bool    dir  = flagged && a.dirichlet[dof] != 0;
                 const double  val  = sb[t];
                 double*       dst  = dof < a.n_owned_dofs ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
@@ -625,6 +599,9 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             }
         }
         stageFence(); // the buffers are rewritten by the next batch
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+            ids_cur[k] = ids_nxt[k];
     }
 }
 
@@ -634,6 +611,8 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     using Cfg = FastCfg< K, P, NQ >;
     if (a.elem_count <= 0)
         return 0;
+    if (!a.dense) // unknowns are a strict subset / permutation of the node's dofs: generic kernel
+        return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);
     K kern{};
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
