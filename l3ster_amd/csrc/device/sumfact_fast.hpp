@@ -559,6 +559,16 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             }
         }
         stageFence();
+        // bufA is free now: stash this element's node ids there in local-node order for the scatter (LDS latency instead
+        // of a dependent global load per scatter round)
+        uint32_t* const idsL = reinterpret_cast< uint32_t* >(bufA);
+        if (on_nn && act)
+        {
+#pragma unroll
+            for (int k = 0; k < N1; ++k)
+                idsL[i1 + N1 * (j1 + N1 * k)] = ids_cur[k];
+        }
+        stageFence();
         loadIds(batch + gridDim.x, ids_nxt); // next element's node ids: in flight behind the scatter
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
         // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
@@ -566,13 +576,13 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         {
             const double*   sb      = reinterpret_cast< const double* >(bufB);
             const int64_t   el      = elemOf(batch);
-            const uint32_t* en      = a.elem_nodes + el * NN;
             const bool      flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[el] != 0;
-            for (int t = l; t < NN * U; t += TEAM) // kept rolled: unrolling the 28 rounds costs registers (spills)
+#pragma unroll 4
+            for (int t = l; t < NN * U; t += TEAM)
             {
                 const int     nl   = t / U;
                 const int     o    = t - nl * U;
-                const int64_t node = en[nl];
+                const int64_t node = idsL[nl];
                 const int64_t dof  = node * U + o;
                 const bool    dir  = flagged && a.dirichlet[dof] != 0;
                 const double  val  = sb[t];
