@@ -113,7 +113,11 @@ struct FastCfg
     static constexpr int NG = (NF + 1) / 2; // field groups of 2 (16-byte LDS accesses); last may be half used
     static constexpr int UG = (U + 1) / 2;
     // LDS array strides: point (c, b, a) lives at a*PS + b*M + c (in 16-byte units within a field group)
+#ifdef L3K_FAST_PS
+    static constexpr int PS = M == 7 ? L3K_FAST_PS : M * M, OS = PS * M;
+#else
     static constexpr int PS = M * M, OS = PS * M;
+#endif
     static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
     // per team: bufA | bufB (NG groups of OS double2 each) | vertices
     static constexpr int    BUF_D    = 2 * NG * OS;
