@@ -176,19 +176,22 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
     const int64_t n_owned_nodes = a.n_owned_dofs / U;
     auto          elemOf = [&](int64_t batch) { return a.elem_begin + batch * EW + team; };
     auto valid   = [&](int64_t batch) { return batch < n_batches && on_nn && (batch * EW + team) < a.elem_count; };
-    auto loadIds = [&](int64_t batch, uint32_t (&ids)[N1]) {
+    const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
+    auto       loadIds    = [&](int64_t batch, uint32_t (&ids)[N1], uint32_t& flag) {
+        flag = 0;
         if (valid(batch))
         {
             const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + i1 + N1 * j1;
 #pragma unroll
             for (int k = 0; k < N1; ++k)
                 ids[k] = en[k * N1 * N1];
+            if (have_flags) // "element touches a Dirichlet dof": fetched with the ids, one element ahead of its use
+                flag = a.elem_flags[elemOf(batch)];
         }
     };
-    auto loadX = [&](int64_t batch, const uint32_t (&ids)[N1]) {
+    auto loadX = [&](int64_t batch, const uint32_t (&ids)[N1], bool flagged) {
         if (!valid(batch))
             return;
-        const bool flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[elemOf(batch)] != 0;
         // node-interleaved dofs with the kernel's unknowns = all dofs of a node (the launcher sends every other layout
         // to the generic kernel): 16-byte vector loads, adjacent lanes read adjacent nodes
         // (dofs/NodeToDofMap.hpp:250-264 layout)
@@ -219,8 +222,13 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         }
     };
 
-    int64_t batch = blockIdx.x;
-    loadIds(batch, ids_cur);
+    // lane-dependent table entries are vector loads from the kernel-argument segment: read them once
+    const double eta_l = qp[qa < NQ ? qa : 0], zeta_l = qp[qb < NQ ? qb : 0];
+    const double wyz_l = qw[qa < NQ ? qa : 0] * qw[qb < NQ ? qb : 0];
+
+    int64_t  batch = blockIdx.x;
+    uint32_t flag_cur, flag_nxt = 0;
+    loadIds(batch, ids_cur, flag_cur);
 
     for (; batch < n_batches; batch += gridDim.x)
     {
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
-        loadX(batch, ids_cur);
+        loadX(batch, ids_cur, flag_cur != 0);
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
         double u0[N1][2 * NG];
         if (on_nn && act)
@@ -385,9 +393,9 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
         if (on_qq && act)
         {
-            const double wyz = qw[qa] * qw[qb];
+            const double wyz = wyz_l;
             double       G[6][3];
-            hexPencilGeom(vs, qp[qa], qp[qb], G);
+            hexPencilGeom(vs, eta_l, zeta_l, G);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
             {
@@ -573,14 +581,14 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                 idsL[i1 + N1 * (j1 + N1 * k)] = ids_cur[k];
         }
         stageFence();
-        loadIds(batch + gridDim.x, ids_nxt); // next element's node ids: in flight behind the scatter
+        loadIds(batch + gridDim.x, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
         // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
         if (act)
         {
             const double*   sb      = reinterpret_cast< const double* >(bufB);
             const int64_t   el      = elemOf(batch);
-            const bool      flagged = a.dirichlet != nullptr && a.elem_flags != nullptr && a.elem_flags[el] != 0;
+            const bool flagged = flag_cur != 0;
 #pragma unroll 4
             for (int t = l; t < NN * U; t += TEAM)
             {
@@ -616,6 +624,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
 #pragma unroll
         for (int k = 0; k < N1; ++k)
             ids_cur[k] = ids_nxt[k];
+        flag_cur = flag_nxt;
     }
 }
 
