@@ -1,0 +1,155 @@
+// operator.hpp -- C++ host-side mirror of the reference's interface for the hot path, on top of the C ABI (l3k.h).
+//
+// The reference is C++ (header-only); this header gives its maintainers the same vocabulary over libl3k.so:
+//   l3k::CubeMesh                ~ generateAndDistributeMesh<order>(makeCubeMesh(...))   comm/DistributeMesh.hpp:284-299
+//   l3k::MatrixFreeSystem        ~ algsys::MatrixFreeSystem                               algsys/MatrixFreeSystem.hpp:19-249
+//       .apply(X, Y, alpha, beta)   ~ Operator::apply                                      :34-41
+//       .diagAndRhs(...)            ~ endAssembly() -> computeDiagAndRhs                   :877-941
+//       .assembleLocal(...)         ~ assembleLocalSystem                                  algsys/AssembleLocalSystem.hpp:234-256
+// Errors: the reference throws std::runtime_error from util::throwingAssert (util/Assertion.hpp:88-95); so does this
+// wrapper, with the text of l3k_last_error().  RAII handles, no torch, no other dependency than l3k.h + the HIP runtime
+// of the caller for device memory.
+#ifndef L3K_OPERATOR_HPP
+#define L3K_OPERATOR_HPP
+
+#include "l3k.h"
+
+#include <array>
+#include <cstdint>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace l3k
+{
+inline void check(int rc)
+{
+    if (rc != 0)
+        throw std::runtime_error{std::string{"libl3k: "} + l3k_last_error()};
+}
+
+// AssemblyOptions, algsys/AssembleLocalSystem.hpp:24-49
+struct AssemblyOptions
+{
+    int value_order = 1, derivative_order = 0, eval_strategy = 0;
+};
+
+class Context
+{
+public:
+    explicit Context(int hip_device = 0, void* hip_stream = nullptr) { check(l3k_ctx_create(hip_device, hip_stream, &m_ctx)); }
+    Context(const Context&)            = delete;
+    Context& operator=(const Context&) = delete;
+    ~Context() { l3k_ctx_destroy(m_ctx); }
+    void     setStream(void* hip_stream) { check(l3k_ctx_set_stream(m_ctx, hip_stream)); }
+    void     synchronize() { check(l3k_ctx_synchronize(m_ctx)); }
+    l3k_ctx* get() const { return m_ctx; }
+
+private:
+    l3k_ctx* m_ctx{};
+};
+
+// One rank's block of the synthetic structured hex mesh (host arrays, reference numbering conventions)
+class CubeMesh
+{
+public:
+    CubeMesh(std::array< int, 3 > ne, int order, std::array< int, 3 > parts = {1, 1, 1}, int rank = 0, double perturb = 0.)
+    {
+        check(l3k_cube_partition_create(ne.data(), order, parts.data(), rank, perturb, &m_mesh));
+        check(l3k_hostmesh_view_get(m_mesh, &m_view));
+    }
+    CubeMesh(const CubeMesh&)            = delete;
+    CubeMesh& operator=(const CubeMesh&) = delete;
+    ~CubeMesh() { l3k_hostmesh_destroy(m_mesh); }
+    const l3k_hostmesh_view& view() const { return m_view; }
+    int64_t                  nLocalNodes() const { return m_view.n_owned_nodes + m_view.n_ghost_nodes; }
+    // BCDefinition::defineDirichlet(boundary_ids, {unknowns}) as a byte mask over local dofs; sides as in
+    // mesh/ElementTraits.hpp:84-95 (bit s of `sides`)
+    std::vector< uint8_t > dirichletMask(int dofs_per_node, std::span< const int > unknowns, unsigned sides = 0x3f) const
+    {
+        std::vector< uint8_t > mask(static_cast< size_t >(nLocalNodes()) * dofs_per_node, 0);
+        for (int64_t n = 0; n < nLocalNodes(); ++n)
+            if (m_view.node_boundary[n] & sides)
+                for (int u : unknowns)
+                    mask[n * dofs_per_node + u] = 1;
+        return mask;
+    }
+
+private:
+    l3k_hostmesh*     m_mesh{};
+    l3k_hostmesh_view m_view{};
+};
+
+class DeviceMesh
+{
+public:
+    DeviceMesh(Context& ctx, const CubeMesh& mesh, int dofs_per_node, const uint8_t* dirichlet = nullptr) : m_dpn{dofs_per_node}
+    {
+        const auto&         v = mesh.view();
+        const l3k_mesh_desc d{v.dim, v.order, v.n_elems, v.n_interior_elems, v.elem_nodes, v.elem_verts, v.n_owned_nodes,
+                              v.n_ghost_nodes, dofs_per_node, dirichlet};
+        check(l3k_mesh_create(ctx.get(), &d, &m_mesh));
+        m_owned = v.n_owned_nodes * dofs_per_node;
+        m_ctx   = ctx.get();
+    }
+    DeviceMesh(const DeviceMesh&)            = delete;
+    DeviceMesh& operator=(const DeviceMesh&) = delete;
+    ~DeviceMesh() { l3k_mesh_destroy(m_mesh); }
+    l3k_mesh* get() const { return m_mesh; }
+    l3k_ctx*  ctx() const { return m_ctx; }
+    int64_t   nOwnedDofs() const { return m_owned; }
+
+private:
+    l3k_mesh* m_mesh{};
+    l3k_ctx*  m_ctx{};
+    int64_t   m_owned{};
+    int       m_dpn{};
+};
+
+// algsys::MatrixFreeSystem for one rank without ghosts.  Kernel = registered functor id + POD parameter block
+// (l3ster_amd/csrc/user_kernels.hpp); vectors are DEVICE pointers, column-major with leading dimension.
+class MatrixFreeSystem
+{
+public:
+    template < typename KernelParamBlock >
+    MatrixFreeSystem(const DeviceMesh& mesh, int kernel_id, const KernelParamBlock& params, AssemblyOptions opts = {},
+                     std::span< const int > field_inds = {}, int n_rhs = 1)
+    {
+        const l3k_asmopts o{opts.value_order, opts.derivative_order, opts.eval_strategy};
+        check(l3k_mf_create(mesh.ctx(), mesh.get(), kernel_id, &params, sizeof params, &o,
+                            field_inds.empty() ? nullptr : field_inds.data(), n_rhs, &m_mf));
+    }
+    MatrixFreeSystem(const DeviceMesh& mesh, int kernel_id, AssemblyOptions opts = {}, int n_rhs = 1)
+    {
+        const l3k_asmopts o{opts.value_order, opts.derivative_order, opts.eval_strategy};
+        check(l3k_mf_create(mesh.ctx(), mesh.get(), kernel_id, nullptr, 0, &o, nullptr, n_rhs, &m_mf));
+    }
+    MatrixFreeSystem(const MatrixFreeSystem&)            = delete;
+    MatrixFreeSystem& operator=(const MatrixFreeSystem&) = delete;
+    ~MatrixFreeSystem() { l3k_mf_destroy(m_mf); }
+
+    void setFields(const double* d_soa, size_t ld) { check(l3k_mf_set_fields(m_mf, d_soa, ld)); } // post::FieldAccess
+    void setTime(double t) { check(l3k_mf_set_time(m_mf, t)); }
+    // Y <- alpha*A*X + beta*Y (Operator::apply; the operator is symmetric, `mode` is ignored by the reference too)
+    void apply(const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols = 1, double alpha = 1., double beta = 0.) const
+    {
+        check(l3k_mf_apply(m_mf, d_x, ldx, d_y, ldy, ncols, alpha, beta));
+    }
+    // diag(A) and rhs with Dirichlet lifting; the caller zeroes d_diag / d_rhs first (computeDiagAndRhs :921-923)
+    void diagAndRhs(const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs, size_t ldr) const
+    {
+        check(l3k_mf_diag_rhs(m_mf, 2, d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, nullptr, nullptr, 0, 1));
+    }
+    // K_e (row-major Nd x Nd), F_e (column-major Nd x n_rhs) of elements [first, first+count)
+    void assembleLocal(int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum = nullptr) const
+    {
+        check(l3k_local_assemble(m_mf, first, count, d_K, d_F, d_checksum));
+    }
+    l3k_mf* get() const { return m_mf; }
+
+private:
+    l3k_mf* m_mf{};
+};
+} // namespace l3k
+#endif

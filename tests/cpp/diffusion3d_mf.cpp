@@ -1,0 +1,125 @@
+// diffusion3d_mf.cpp -- the C++ host shim (include/l3k/operator.hpp) used the way the reference's own tests use its
+// API: (1) single distorted element: matrix-free apply == K_e * x with K_e from LocalAssembly (the property
+// tests/LocalOperatorTests.cpp:3-95 checks, < 1e-8); (2) a Dirichlet-constrained mesh operator is symmetric,
+// <A x, z> = <x, A z> (Operator::apply ignores `mode`, algsys/MatrixFreeSystem.hpp:34-41).
+// Build: hipcc -std=c++20 -Iinclude tests/cpp/diffusion3d_mf.cpp -Ll3ster_amd/lib -ll3k -o /tmp/diffusion3d_mf
+#include "l3k/operator.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#define HIP_CHECK(x)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if ((x) != hipSuccess)                                                                                         \
+        {                                                                                                              \
+            std::fprintf(stderr, "HIP error at %s:%d\n", __FILE__, __LINE__);                                          \
+            return 2;                                                                                                  \
+        }                                                                                                              \
+    } while (0)
+
+struct DevVec
+{
+    double* p{};
+    size_t  n{};
+    explicit DevVec(size_t n_) : n{n_} { (void)hipMalloc(reinterpret_cast< void** >(&p), n * sizeof(double)); }
+    ~DevVec() { (void)hipFree(p); }
+    void up(const std::vector< double >& h) { (void)hipMemcpy(p, h.data(), n * sizeof(double), hipMemcpyHostToDevice); }
+    std::vector< double > down() const
+    {
+        std::vector< double > h(n);
+        (void)hipMemcpy(h.data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
+        return h;
+    }
+};
+
+int main()
+{
+    struct DiffusionParams
+    {
+        double k, s;
+    } params{0.7, 1.0};
+    l3k::Context ctx{0};
+    auto         prng = std::mt19937_64{42};
+    auto         dist = std::uniform_real_distribution< double >{-1., 1.};
+    int          failures = 0;
+
+    { // (1) one element, order 3: apply == K_e x
+        constexpr int         p = 3, U = 4, N = (p + 1) * (p + 1) * (p + 1), Nd = N * U;
+        l3k::CubeMesh         mesh{{1, 1, 1}, p, {1, 1, 1}, 0, 0.};
+        l3k::DeviceMesh       dmesh{ctx, mesh, U};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        std::vector< double > x(Nd);
+        for (auto& v : x)
+            v = dist(prng);
+        DevVec dx{Nd}, dy{Nd}, dK{size_t(Nd) * Nd}, dF{Nd};
+        dx.up(x);
+        sys.apply(dx.p, Nd, dy.p, Nd);
+        sys.assembleLocal(0, 1, dK.p, dF.p);
+        ctx.synchronize();
+        const auto y = dy.down();
+        const auto K = dK.down();
+        double     err = 0., nrm = 0.;
+        for (int i = 0; i < Nd; ++i)
+        {
+            double kx = 0.;
+            for (int j = 0; j < Nd; ++j)
+                kx += K[size_t(i) * Nd + j] * x[mesh.view().elem_nodes[j / U] * U + j % U]; // element-local -> global dof
+            const double yi = y[mesh.view().elem_nodes[i / U] * U + i % U];
+            err += (yi - kx) * (yi - kx);
+            nrm += kx * kx;
+        }
+        std::printf("single element: |y - K_e x| / |K_e x| = %.3e\n", std::sqrt(err / nrm));
+        failures += !(std::sqrt(err / nrm) < 1e-12);
+    }
+    { // (2) 4^3 elements, order 4, Dirichlet on unknown 0: symmetry
+        constexpr int         p = 4, U = 4;
+        l3k::CubeMesh         mesh{{4, 4, 4}, p, {1, 1, 1}, 0, 0.1};
+        const int             unknowns[] = {0};
+        const auto            mask = mesh.dirichletMask(U, unknowns);
+        l3k::DeviceMesh       dmesh{ctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        const size_t          n = static_cast< size_t >(dmesh.nOwnedDofs());
+        std::vector< double > x(n), z(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            x[i] = dist(prng);
+            z[i] = dist(prng);
+        }
+        DevVec dx{n}, dz{n}, dax{n}, daz{n};
+        dx.up(x);
+        dz.up(z);
+        sys.apply(dx.p, n, dax.p, n);
+        sys.apply(dz.p, n, daz.p, n);
+        ctx.synchronize();
+        const auto ax = dax.down(), az = daz.down();
+        double     s1 = 0., s2 = 0.;
+        for (size_t i = 0; i < n; ++i)
+        {
+            s1 += ax[i] * z[i];
+            s2 += x[i] * az[i];
+        }
+        std::printf("symmetry: <Ax,z> = %.15e, <x,Az> = %.15e\n", s1, s2);
+        failures += !(std::fabs(s1 - s2) < 1e-11 * std::fabs(s1));
+    }
+    try
+    { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)
+        l3k::CubeMesh         mesh{{1, 1, 1}, 2};
+        l3k::DeviceMesh       dmesh{ctx, mesh, 4};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        DevVec                a{size_t(dmesh.nOwnedDofs()) * 2}, b{size_t(dmesh.nOwnedDofs()) * 2};
+        sys.apply(a.p, dmesh.nOwnedDofs(), b.p, dmesh.nOwnedDofs(), 2);
+        std::printf("expected an exception\n");
+        ++failures;
+    }
+    catch (const std::runtime_error& e)
+    {
+        std::printf("error reported as exception: %s\n", e.what());
+    }
+    std::printf(failures ? "FAILED\n" : "OK\n");
+    return failures;
+}
