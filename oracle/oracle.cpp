@@ -573,8 +573,39 @@ inline void basisBlock(const KernelEval& ke, int dim, int E, int U, double bv, c
 // ---------------------------------------------------------------------------------------------------------------------
 // Sum-factorisation sweeps.  algsys/SumFactorization.hpp:67-86: out = in^T * M on column-major maps:
 // in is n_in x C (col-major), M is n_in x n_out (row-major), out is C x n_out (col-major).
+template < int NI, int NO >
+void sweepStdFixed(const double* in, int C, const double* M, double* out, bool accumulate)
+{
+    for (int c = 0; c < C; ++c)
+    {
+        const double* col = in + static_cast< size_t >(NI) * c;
+        double        acc[NO];
+        for (int q = 0; q < NO; ++q)
+            acc[q] = 0.;
+        for (int b = 0; b < NI; ++b)
+        {
+            const double v = col[b];
+            for (int q = 0; q < NO; ++q)
+                acc[q] += v * M[b * NO + q];
+        }
+        if (accumulate)
+            for (int q = 0; q < NO; ++q)
+                out[c + static_cast< size_t >(C) * q] += acc[q];
+        else
+            for (int q = 0; q < NO; ++q)
+                out[c + static_cast< size_t >(C) * q] = acc[q];
+    }
+}
 void sweepStd(const double* in, int n_in, int C, const double* M, int n_out, double* out, bool accumulate)
 {
+    // same arithmetic per entry (sum over b in ascending order); fixed-size instantiations only help the compiler
+#define L3K_ORC_CASE(NI, NO)                                                                                           \
+    if (n_in == NI && n_out == NO)                                                                                     \
+        return sweepStdFixed< NI, NO >(in, C, M, out, accumulate);
+    L3K_ORC_CASE(2, 2) L3K_ORC_CASE(3, 3) L3K_ORC_CASE(4, 4) L3K_ORC_CASE(5, 5) L3K_ORC_CASE(6, 6) L3K_ORC_CASE(7, 7)
+    L3K_ORC_CASE(2, 5) L3K_ORC_CASE(2, 7) L3K_ORC_CASE(5, 2) L3K_ORC_CASE(7, 2) L3K_ORC_CASE(2, 3) L3K_ORC_CASE(3, 2)
+    L3K_ORC_CASE(4, 7) L3K_ORC_CASE(7, 4) L3K_ORC_CASE(2, 4) L3K_ORC_CASE(4, 2) L3K_ORC_CASE(2, 6) L3K_ORC_CASE(6, 2)
+#undef L3K_ORC_CASE
     for (int q = 0; q < n_out; ++q)
         for (int c = 0; c < C; ++c)
         {
@@ -710,7 +741,8 @@ void sumFactBack(const SweepSet& s, int dim, int nf, const double* fill, std::ve
     const size_t sz = static_cast< size_t >(ipow(std::max(n, nq), dim)) * nf;
     for (int i = 0; i <= dim; ++i)
         r[i].assign(sz, 0.);
-    std::vector< double > temp(sz, 0.);
+    thread_local std::vector< double > temp;
+    temp.assign(sz, 0.);
     if (dim == 2)
     {
         std::copy(fill, fill + static_cast< size_t >(n) * n * nf, r[1].begin());
@@ -786,7 +818,8 @@ void sumFactElement(const SumFactCtx& c, const double* verts, const double* fill
     const int dim = c.dim, nq = c.nq, E = c.k->kp.E, U = c.k->kp.U, F = c.k->kp.F, R = c.R;
     const int nops = U * R, nf = nops + F, nqp = ipow(nq, dim), nv = 1 << dim;
 
-    std::vector< double > back[4], geom[4], fwd[4];
+    // scratch is kept per thread (the reference keeps it on the stack, algsys/SumFactorization.hpp:838,865)
+    thread_local std::vector< double > back[4], geom[4], fwd[4];
     sumFactBack(c.sw, dim, nf, fill, back);
     // geometry: fill[i + nv*s] = vertex[i][s]  (:510-518, :526-535), num_fields = dim
     std::vector< double > gfill(static_cast< size_t >(nv) * dim);
