@@ -589,34 +589,88 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             const double*   sb      = reinterpret_cast< const double* >(bufB);
             const int64_t   el      = elemOf(batch);
             const bool flagged = flag_cur != 0;
-#pragma unroll 4
-            for (int t = l; t < NN * U; t += TEAM)
+            // measured (profiles/r01_kbench_scatter_variants.log): two unknowns per lane and round halve the loop overhead
+            // and give 16-byte stores on exclusive nodes, but halve the density of the atomic wave-instructions; it wins
+            // where exclusive nodes are many (order >= 6: 36 % of an element's nodes), loses at order 4 (22 %)
+            if constexpr (P >= 6)
             {
-                const int     nl   = t / U;
-                const int     o    = t - nl * U;
-                const int64_t node = idsL[nl];
-                const int64_t dof  = node * U + o;
-                const bool    dir  = flagged && a.dirichlet[dof] != 0;
-                const double  val  = sb[t];
-                double*       dst  = dof < a.n_owned_dofs ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                if (a.dbg & 1)
+                // two unknowns (16 bytes) per lane and round: half the address / branch overhead, 16-byte stores on
+                // exclusive nodes; consecutive lanes still cover consecutive dofs
+                const double2* sb2 = reinterpret_cast< const double2* >(sb);
+#pragma unroll 2
+                for (int t = l; t < NN * (U / 2); t += TEAM)
                 {
-                    if (val == 1.2345e300)
-                        *dst = val;
-                }
-                else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
-                {
-                    // touched by this element only: y = alpha*(A x) + beta*y written here, no atomic, and for beta = 0
-                    // no read either (these rows are skipped by the pre-scaling pass, l3k_mf_scale)
-                    const double contrib = dir ? 0. : val; // Dirichlet dofs are skipped (MatrixFreeSystem.hpp:517-536)
-                    *dst = a.beta == 0. ? contrib : contrib + a.beta * *dst;
-                }
-                else if (!dir)
-                {
-                    if (a.dbg & 16)
-                        *dst += val;
+                    const int     nl   = t / (U / 2);
+                    const int     o    = 2 * (t - nl * (U / 2));
+                    const int64_t node = idsL[nl];
+                    const int64_t dof  = node * U + o;
+                    const double2 val  = sb2[t];
+                    const bool    d0   = flagged && a.dirichlet[dof] != 0, d1 = flagged && a.dirichlet[dof + 1] != 0;
+                    double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                    if (a.dbg & 1)
+                    {
+                        if (val.x == 1.2345e300)
+                            *dst = val.x;
+                    }
+                    else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
+                    {
+                        // touched by this element only: y = alpha*(A x) + beta*y written here, no atomic, and for beta = 0
+                        // no read either (these rows are skipped by the pre-scaling pass, l3k_mf_scale); Dirichlet dofs
+                        // contribute nothing (MatrixFreeSystem.hpp:517-536)
+                        double2 out = make_double2(d0 ? 0. : val.x, d1 ? 0. : val.y);
+                        if (a.beta != 0.)
+                        {
+                            const double2 old = *reinterpret_cast< const double2* >(dst);
+                            out.x += a.beta * old.x;
+                            out.y += a.beta * old.y;
+                        }
+                        *reinterpret_cast< double2* >(dst) = out;
+                    }
                     else
-                        unsafeAtomicAdd(dst, val);
+                    {
+                        if (!d0)
+                        {
+                            if (a.dbg & 16)
+                                dst[0] += val.x;
+                            else
+                                unsafeAtomicAdd(dst, val.x);
+                        }
+                        if (!d1)
+                        {
+                            if (a.dbg & 16)
+                                dst[1] += val.y;
+                            else
+                                unsafeAtomicAdd(dst + 1, val.y);
+                        }
+                    }
+                }
+            }
+            else
+            {
+#pragma unroll 4
+                for (int t = l; t < NN * U; t += TEAM)
+                {
+                    const int     nl   = t / U;
+                    const int     o    = t - nl * U;
+                    const int64_t node = idsL[nl];
+                    const int64_t dof  = node * U + o;
+                    const bool    dir  = flagged && a.dirichlet[dof] != 0;
+                    const double  val  = sb[t];
+                    double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                    if (a.dbg & 1)
+                    {
+                        if (val == 1.2345e300)
+                            *dst = val;
+                    }
+                    else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
+                        *dst = (dir ? 0. : val) + (a.beta == 0. ? 0. : a.beta * *dst);
+                    else if (!dir)
+                    {
+                        if (a.dbg & 16)
+                            *dst += val;
+                        else
+                            unsafeAtomicAdd(dst, val);
+                    }
                 }
             }
         }
