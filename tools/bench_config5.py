@@ -1,0 +1,65 @@
+"""BASELINE.json config 5 on one GPU: advection-diffusion-reaction in first-order least-squares form (unknowns c, q;
+velocity = 3 interpolated fields, the karman-style "kernel reads interpolated field values"), hex order 4, Jacobi-PCG
+driven by the matrix-free apply.  Reports DOF/s per apply inside the solve and the iteration count.
+    python tools/bench_config5.py [--ne 64] [--order 4] [--tol 1e-6]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from l3ster_amd import solve, system  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ne", type=int, default=64)
+ap.add_argument("--order", type=int, default=4)
+ap.add_argument("--tol", type=float, default=1e-6)
+a = ap.parse_args()
+torch.cuda.set_device(0)
+ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+p, U, kid = a.order, 4, system.KERNEL_ADVDIFF3D
+part = system.CubePartition(a.ne, p, perturb=0.1)
+mask = part.dirichlet_mask(U)
+mesh = system.DeviceMesh(ctx, part, U, mask)
+mf = system.MatrixFreeSystem(mesh, kid, [1.0, 0.5, 1.0])  # k, sigma, s
+# smooth analytic velocity sampled at the nodes' reference grid position (synthetic field data, SoA [3][n_nodes])
+Nx = p * a.ne + 1
+gid = torch.as_tensor(part.node_grid_id, device="cuda")
+gx, gy, gz = (gid % Nx).double() / (Nx - 1), ((gid // Nx) % Nx).double() / (Nx - 1), (gid // (Nx * Nx)).double() / (Nx - 1)
+fields = torch.stack([0.5 * torch.sin(np.pi * gy), 0.25 * torch.cos(np.pi * gx), 0.1 * gz]).contiguous()
+mf.set_fields(fields)
+diag, rhs = mf.diag_rhs(None)  # homogeneous Dirichlet c = 0
+minv = solve.jacobi_inverse(diag)
+x = torch.zeros_like(diag)
+n_apply = [0]
+
+
+def apply(v, out):
+    n_apply[0] += 1
+    mf.apply(v[None, :], out[None, :])
+
+
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = solve.cg(apply, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+dofs = part.n_global_nodes * U
+# apply alone, same operator
+y = torch.empty_like(x)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    mf.apply(x[None, :], y[None, :])
+e1.record()
+torch.cuda.synchronize()
+ms_apply = e0.elapsed_time(e1) / 10
+print(json.dumps({"config": f"advection-diffusion 3D (F=3 fields), hex {a.ne}^3, order {p}, Jacobi-PCG rel tol {a.tol}",
+                  "dofs": dofs, "iterations": res.num_iters, "achieved_tol": res.tol, "solve_s": dt, "applies": n_apply[0],
+                  "dof_per_s_inside_solve": dofs * n_apply[0] / dt, "ms_per_apply_alone": ms_apply,
+                  "dof_per_s_apply_alone": dofs / (ms_apply * 1e-3)}))
