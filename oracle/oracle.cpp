@@ -199,6 +199,7 @@ struct KIn
     const double* fd[3]; // [D][F]
     double        x, y, z, t;
     const double* kp;    // kernel parameter block or nullptr
+    double        normal[3]; // outward unit normal (boundary kernels only, common/KernelInterface.hpp:48-57)
 };
 struct KOut
 {
@@ -308,10 +309,37 @@ void kAdvDiff3D(const KIn& in, KOut& o)
     o.op(2, 6, 1) = -1.;
 }
 
+// Boundary equation kernels (wrapBoundaryEquationKernel: the input additionally carries the outward normal)
+// tests/Kernels.hpp:120-128: q . n = 0
+void kAdiabatic2D(const KIn& in, KOut& o)
+{
+    o.op(0, 0, 1) = in.normal[0];
+    o.op(0, 0, 2) = in.normal[1];
+}
+// 3-D twin of the above for the hex path (unknowns T, qx, qy, qz)
+void kAdiabatic3D(const KIn& in, KOut& o)
+{
+    o.op(0, 0, 1) = in.normal[0];
+    o.op(0, 0, 2) = in.normal[1];
+    o.op(0, 0, 3) = in.normal[2];
+}
+// Robin condition in first-order form, q . n + h T = h T_inf (synthetic; exercises A0 on the primary unknown and a
+// non-zero boundary rhs).  kp = {h, T_inf}
+void kRobin3D(const KIn& in, KOut& o)
+{
+    const double h = in.kp ? in.kp[0] : 1., tinf = in.kp ? in.kp[1] : 0.;
+    o.op(0, 0, 0) = h;
+    o.op(0, 0, 1) = in.normal[0];
+    o.op(0, 0, 2) = in.normal[1];
+    o.op(0, 0, 3) = in.normal[2];
+    o.f(0)        = h * tinf;
+}
+
 struct KernelEntry
 {
     KParams kp;
     KFun    fun;
+    bool    boundary = false;
 };
 const KernelEntry* getKernel(int id)
 {
@@ -319,7 +347,10 @@ const KernelEntry* getKernel(int id)
                                         {{3, 7, 4, 1}, kDiffusion3DVar},
                                         {{2, 4, 3, 0}, kDiffusion2D},
                                         {{2, 4, 3, 1}, kDiffusion2DVar},
-                                        {{3, 7, 4, 3}, kAdvDiff3D}};
+                                        {{3, 7, 4, 3}, kAdvDiff3D},
+                                        {{2, 1, 3, 0}, kAdiabatic2D, true},
+                                        {{3, 1, 4, 0}, kAdiabatic3D, true},
+                                        {{3, 1, 4, 0}, kRobin3D, true}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];
@@ -492,6 +523,170 @@ RefBasis makeRefBasis(int dim, int p, int nq)
     return rb;
 }
 
+// Reference boundary element -> element side: x_side = rot * (u, [v,] 0) + trans.
+// mapping/ReferenceBoundaryToSideMapping.hpp:15-52 with math/RotationMatrix.hpp:10-79 (sin/cos of the angle evaluated
+// like the reference does, so sin(pi) is ~1.2e-16 and not 0).
+struct SideMap
+{
+    double rot[9]; // row-major dim x dim
+    double trans[3];
+};
+SideMap sideMap(int dim, int side)
+{
+    SideMap      m{};
+    const double pi = 3.141592653589793238462643383279502884;
+    const auto rotX = [&](double a) {
+        const double sn = std::sin(a), cs = std::cos(a);
+        const double r[9] = {1., 0., 0., 0., cs, -sn, 0., sn, cs};
+        std::copy(r, r + 9, m.rot);
+    };
+    const auto rotY = [&](double a) {
+        const double sn = std::sin(a), cs = std::cos(a);
+        const double r[9] = {cs, 0., sn, 0., 1., 0., -sn, 0., cs};
+        std::copy(r, r + 9, m.rot);
+    };
+    const auto rot2 = [&](double a) {
+        const double sn = std::sin(a), cs = std::cos(a);
+        const double r[4] = {cs, sn, -sn, cs};
+        std::copy(r, r + 4, m.rot);
+    };
+    const auto ident = [&] {
+        for (int i = 0; i < dim; ++i)
+            m.rot[i * dim + i] = 1.;
+    };
+    if (dim == 3)
+        switch (side)
+        {
+        case 0: rotX(pi); m.trans[2] = -1.; break;
+        case 1: ident(); m.trans[2] = 1.; break;
+        case 2: rotX(-pi / 2.); m.trans[1] = -1.; break;
+        case 3: rotX(pi / 2.); m.trans[1] = 1.; break;
+        case 4: rotY(pi / 2.); m.trans[0] = -1.; break;
+        default: rotY(-pi / 2.); m.trans[0] = 1.; break;
+        }
+    else
+        switch (side)
+        {
+        case 0: rot2(pi); m.trans[1] = -1.; break;
+        case 1: ident(); m.trans[1] = 1.; break;
+        case 2: rot2(pi / 2.); m.trans[0] = -1.; break;
+        default: rot2(-pi / 2.); m.trans[0] = 1.; break;
+        }
+    return m;
+}
+
+// Reference basis at the quadrature of one element side (basisfun/ReferenceElementBasisAtQuadrature.hpp:21-97): the
+// (dim-1)-dimensional Gauss rule (same 1-D size nq, xi slowest) mapped onto the side, the FULL element basis evaluated
+// there (basisfun/ReferenceBasisFunction.hpp:74-153).
+RefBasis makeSideBasis(int dim, int p, int nq, int side)
+{
+    const Tables1D t = makeTables(p, nq);
+    const SideMap  sm = sideMap(dim, side);
+    RefBasis       rb;
+    rb.dim = dim;
+    rb.N   = ipow(p + 1, dim);
+    rb.nqp = ipow(nq, dim - 1);
+    rb.vals.assign(static_cast< size_t >(rb.nqp) * rb.N, 0.);
+    rb.ders.assign(static_cast< size_t >(rb.nqp) * dim * rb.N, 0.);
+    rb.weights.assign(rb.nqp, 0.);
+    rb.points.assign(static_cast< size_t >(rb.nqp) * dim, 0.);
+    const int             n = p + 1;
+    std::vector< double > v(static_cast< size_t >(3) * n, 1.), d(static_cast< size_t >(3) * n, 0.);
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        double bq[3] = {0., 0., 0.}; // point of the reference boundary element, last coordinate 0 (:24-38)
+        double w     = 1.;
+        if (dim == 2)
+        {
+            bq[0] = t.qx[qi];
+            w     = t.qw[qi];
+        }
+        else
+        {
+            bq[0] = t.qx[qi / nq];
+            bq[1] = t.qx[qi % nq];
+            w     = t.qw[qi / nq] * t.qw[qi % nq];
+        }
+        rb.weights[qi] = w;
+        double pt[3]   = {0., 0., 0.};
+        for (int r = 0; r < dim; ++r)
+        {
+            for (int c = 0; c < dim; ++c)
+                pt[r] += sm.rot[r * dim + c] * bq[c];
+            pt[r] += sm.trans[r];
+            rb.points[qi * dim + r] = pt[r];
+            lagrange1d(t.gll, pt[r], &v[static_cast< size_t >(r) * n], &d[static_cast< size_t >(r) * n]);
+        }
+        for (int b = 0; b < rb.N; ++b)
+        {
+            const int bi[3] = {b % n, (b / n) % n, b / (n * n)};
+            double    val   = 1.;
+            for (int a = 0; a < dim; ++a)
+                val *= v[a * n + bi[a]];
+            rb.vals[static_cast< size_t >(qi) * rb.N + b] = val;
+            for (int dd = 0; dd < dim; ++dd)
+            {
+                double dv = 1.;
+                for (int a = 0; a < dim; ++a)
+                    dv *= (a == dd) ? d[a * n + bi[a]] : v[a * n + bi[a]];
+                rb.ders[(static_cast< size_t >(qi) * dim + dd) * rb.N + b] = dv;
+            }
+        }
+    }
+    return rb;
+}
+// mapping/BoundaryIntegralJacobian.hpp:9-29 and mapping/BoundaryNormal.hpp:8-64, J[d][s] = d x_s / d xi_d
+double boundaryJacobian(int dim, int side, const double* J)
+{
+    const SideMap sm = sideMap(dim, side);
+    double        c0[3] = {0., 0., 0.}, c1[3] = {0., 0., 0.}; // J^T * rot.col(0), J^T * rot.col(1)
+    for (int s = 0; s < dim; ++s)
+        for (int dd = 0; dd < dim; ++dd)
+        {
+            c0[s] += J[dd * dim + s] * sm.rot[dd * dim + 0];
+            c1[s] += J[dd * dim + s] * sm.rot[dd * dim + 1];
+        }
+    if (dim == 2)
+        return std::sqrt(c0[0] * c0[0] + c0[1] * c0[1]);
+    const double cr[3] = {c0[1] * c1[2] - c0[2] * c1[1], c0[2] * c1[0] - c0[0] * c1[2], c0[0] * c1[1] - c0[1] * c1[0]};
+    return std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+}
+void boundaryNormal(int dim, int side, const double* J, double* nrm)
+{
+    nrm[0] = nrm[1] = nrm[2] = 0.;
+    if (dim == 2)
+    {
+        switch (side)
+        {
+        case 0: nrm[0] = J[1]; nrm[1] = -J[0]; break;
+        case 1: nrm[0] = -J[1]; nrm[1] = J[0]; break;
+        case 2: nrm[0] = -J[3]; nrm[1] = J[2]; break;
+        default: nrm[0] = J[3]; nrm[1] = -J[2]; break;
+        }
+    }
+    else
+    {
+        const auto cross = [&](int a, int b, double sgn) {
+            const double *ra = J + 3 * a, *rb = J + 3 * b;
+            nrm[0] = sgn * (ra[1] * rb[2] - ra[2] * rb[1]);
+            nrm[1] = sgn * (ra[2] * rb[0] - ra[0] * rb[2]);
+            nrm[2] = sgn * (ra[0] * rb[1] - ra[1] * rb[0]);
+        };
+        switch (side)
+        {
+        case 0: cross(0, 1, -1.); break;
+        case 1: cross(0, 1, 1.); break;
+        case 2: cross(0, 2, 1.); break;
+        case 3: cross(0, 2, -1.); break;
+        case 4: cross(1, 2, -1.); break;
+        default: cross(1, 2, 1.); break;
+        }
+    }
+    const double len = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    for (int s = 0; s < 3; ++s)
+        nrm[s] /= len;
+}
+
 // One quadrature point of the local-element path: mapDomain (mapping/MapReferenceToPhysical.hpp:27-42,69-78:
 // phys_ders = J^{-1} ref_ders, jacobian = det J) + evalKernel (algsys/AssembleLocalSystem.hpp:54-75,218-232).
 struct QpData
@@ -499,17 +694,19 @@ struct QpData
     std::vector< double > phys; // [dim][N]
     double                jac;
 };
-void processQp(const RefBasis&  rb,
+void prepareQp(const RefBasis&  rb,
                int              qi,
                const double*    verts,
                const double*    node_fields,
+               int              F,
                const double*    kparams,
                double           time,
-               KernelEval&      ke,
                QpData&          qd,
-               std::vector< double >& scratch)
+               std::vector< double >& scratch,
+               int              side,
+               KIn&             in)
 {
-    const int     dim = rb.dim, N = rb.N, F = ke.k->kp.F;
+    const int     dim = rb.dim, N = rb.N;
     const double* pt = &rb.points[static_cast< size_t >(qi) * dim];
     double        J[9], Ji[9];
     jacobiMat(dim, verts, pt, J);
@@ -543,7 +740,7 @@ void processQp(const RefBasis&  rb,
     }
     double xyz[3];
     mapToPhysical(dim, verts, pt, xyz);
-    KIn in{};
+    in    = KIn{};
     in.fv = scratch.data();
     for (int s = 0; s < dim; ++s)
         in.fd[s] = scratch.data() + (s + 1) * F;
@@ -552,7 +749,73 @@ void processQp(const RefBasis&  rb,
     in.z  = xyz[2];
     in.t  = time;
     in.kp = kparams;
+    if (side >= 0) // mapBoundary, mapping/MapReferenceToPhysical.hpp:44-89: integration jacobian and normal of the side
+    {
+        qd.jac = boundaryJacobian(dim, side, J);
+        boundaryNormal(dim, side, J, in.normal);
+    }
+}
+void processQp(const RefBasis&  rb,
+               int              qi,
+               const double*    verts,
+               const double*    node_fields,
+               const double*    kparams,
+               double           time,
+               KernelEval&      ke,
+               QpData&          qd,
+               std::vector< double >& scratch,
+               int              side = -1)
+{
+    KIn in;
+    prepareQp(rb, qi, verts, node_fields, ke.k->kp.F, kparams, time, qd, scratch, side, in);
     ke(in);
+}
+
+// Residual kernels (wrapDomainResidualKernel / wrapBoundaryResidualKernel, common/KernelInterface.hpp:121-176): a
+// vector of n_equations values at a point from the interpolated fields, their physical derivatives, the point and (on
+// boundaries) the normal.  Used by computeIntegral / computeNormL2 (post/Integral.hpp, post/NormL2.hpp).
+using RFun = void (*)(const KIn&, double* out);
+// benchmarks/Diffusion3D.hpp:81-103: residuals of the first-order system for fields (T, qx, qy, qz); kp = {k, s}
+void rDiffusion3DError(const KIn& in, double* e)
+{
+    const double k = in.kp ? in.kp[0] : 1., s = in.kp ? in.kp[1] : 1.;
+    e[0] = k * (in.fd[0][1] + in.fd[1][2] + in.fd[2][3]) + s;
+    e[1] = in.fd[0][0] - in.fv[1];
+    e[2] = in.fd[1][0] - in.fv[2];
+    e[3] = in.fd[2][0] - in.fv[3];
+}
+// tests/Diffusion2D.hpp:84-92 (node_dist.back() == 1): error against the exact solution T = x
+void rLinear2DError(const KIn& in, double* e)
+{
+    e[0] = in.fv[0] - in.x;
+    e[1] = in.fv[1] - 1.;
+    e[2] = in.fv[2];
+}
+// 3-D twin: exact solution T = x, q = (1, 0, 0)
+void rLinear3DError(const KIn& in, double* e)
+{
+    e[0] = in.fv[0] - in.x;
+    e[1] = in.fv[1] - 1.;
+    e[2] = in.fv[2];
+    e[3] = in.fv[3];
+}
+// tests/MappingTests.cpp:567-569: integrand 1 (length / area / volume)
+void rUnit(const KIn&, double* e)
+{
+    e[0] = 1.;
+}
+struct ResidualEntry
+{
+    int  dim, E, F;
+    RFun fun;
+};
+const ResidualEntry* getResidual(int id)
+{
+    static const ResidualEntry table[] = {{3, 4, 4, rDiffusion3DError}, {2, 3, 3, rLinear2DError}, {3, 4, 4, rLinear3DError},
+                                          {2, 1, 0, rUnit}, {3, 1, 0, rUnit}};
+    if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
+        return nullptr;
+    return &table[id];
 }
 
 // B_q^T block of one basis function: block[u][e] = phi*A0[e][u] + sum_d dphi_d*A_d[e][u]
@@ -1067,14 +1330,16 @@ int orc_node_location(int dim, int p, const double* verts, int node, double* xyz
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-int orc_assemble_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+int orc_assemble_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
                        const double* kparams, double time, double* K, double* F_e)
 {
     const auto* k = getKernel(kernel_id);
     if (!k)
         return fail(-1, "unknown kernel id");
+    if (k->boundary != (side >= 0))
+        return fail(-1, "domain kernel used on a side or boundary kernel used on a domain");
     const auto [dim, E, U, F] = k->kp;
-    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const RefBasis rb         = side < 0 ? makeRefBasis(dim, p, nq) : makeSideBasis(dim, p, nq, side);
     const int      N = rb.N, Nd = N * U;
     KernelEval     ke{k, R};
     QpData         qd;
@@ -1083,8 +1348,8 @@ int orc_assemble_local(int kernel_id, int p, int nq, int R, const double* verts,
     std::fill(F_e, F_e + static_cast< size_t >(Nd) * R, 0.);
     for (int qi = 0; qi < rb.nqp; ++qi)
     {
-        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
-        if (!(qd.jac > 0.))
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch, side);
+        if (side < 0 && !(qd.jac > 0.))
             return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // AssembleLocalSystem.hpp:249
         const double w = qd.jac * rb.weights[qi], sw = std::sqrt(std::fabs(w)), sgn = w >= 0. ? 1. : -1.;
         // LocalSystemManager::update, AssembleLocalSystem.hpp:146-166
@@ -1121,14 +1386,22 @@ int orc_assemble_local(int kernel_id, int p, int nq, int R, const double* verts,
     return 0;
 }
 
-int orc_apply_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+int orc_assemble_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                       const double* kparams, double time, double* K, double* F_e)
+{
+    return orc_assemble_local_side(-1, kernel_id, p, nq, R, verts, node_fields, kparams, time, K, F_e);
+}
+
+int orc_apply_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
                     const double* kparams, double time, const double* x, double* y)
 {
     const auto* k = getKernel(kernel_id);
     if (!k)
         return fail(-1, "unknown kernel id");
+    if (k->boundary != (side >= 0))
+        return fail(-1, "domain kernel used on a side or boundary kernel used on a domain");
     const auto [dim, E, U, F] = k->kp;
-    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const RefBasis rb         = side < 0 ? makeRefBasis(dim, p, nq) : makeSideBasis(dim, p, nq, side);
     const int      N = rb.N, Nd = N * U;
     KernelEval     ke{k, R};
     QpData         qd;
@@ -1136,8 +1409,8 @@ int orc_apply_local(int kernel_id, int p, int nq, int R, const double* verts, co
     std::fill(y, y + static_cast< size_t >(Nd) * R, 0.);
     for (int qi = 0; qi < rb.nqp; ++qi)
     {
-        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
-        if (!(qd.jac > 0.))
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch, side);
+        if (side < 0 && !(qd.jac > 0.))
             return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // EvaluateLocalOperator.hpp:229
         const double w = qd.jac * rb.weights[qi];
         // fillBatch (:96-127): B_q^T, Nd x E
@@ -1170,15 +1443,23 @@ int orc_apply_local(int kernel_id, int p, int nq, int R, const double* verts, co
     return 0;
 }
 
-int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+int orc_apply_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                    const double* kparams, double time, const double* x, double* y)
+{
+    return orc_apply_local_side(-1, kernel_id, p, nq, R, verts, node_fields, kparams, time, x, y);
+}
+
+int orc_diag_rhs_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
                        const double* kparams, double time, int n_dir, const int* dir_inds, const double* dir_vals,
                        double* diag, double* rhs)
 {
     const auto* k = getKernel(kernel_id);
     if (!k)
         return fail(-1, "unknown kernel id");
+    if (k->boundary != (side >= 0))
+        return fail(-1, "domain kernel used on a side or boundary kernel used on a domain");
     const auto [dim, E, U, F] = k->kp;
-    const RefBasis rb         = makeRefBasis(dim, p, nq);
+    const RefBasis rb         = side < 0 ? makeRefBasis(dim, p, nq) : makeSideBasis(dim, p, nq, side);
     const int      N = rb.N, Nd = N * U;
     KernelEval     ke{k, R};
     QpData         qd;
@@ -1188,8 +1469,8 @@ int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts,
     std::fill(rhs, rhs + static_cast< size_t >(Nd) * R, 0.);
     for (int qi = 0; qi < rb.nqp; ++qi)
     {
-        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch);
-        if (!(qd.jac > 0.))
+        processQp(rb, qi, verts, node_fields, kparams, time, ke, qd, scratch, side);
+        if (side < 0 && !(qd.jac > 0.))
             return fail(-2, "Encountered degenerate element ( |J| <= 0 )"); // EvaluateLocalOperator.hpp:295
         const double w = qd.jac * rb.weights[qi];
         // precomputeDiagRhsImpl, EvaluateLocalOperator.hpp:172-208
@@ -1235,6 +1516,13 @@ int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts,
         }
     }
     return 0;
+}
+
+int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                       const double* kparams, double time, int n_dir, const int* dir_inds, const double* dir_vals,
+                       double* diag, double* rhs)
+{
+    return orc_diag_rhs_local_side(-1, kernel_id, p, nq, R, verts, node_fields, kparams, time, n_dir, dir_inds, dir_vals, diag, rhs);
 }
 
 int orc_apply_sumfact(int kernel_id, int p, int nq, int R, int odd_even, int pass_true_z, const double* verts,
@@ -1390,6 +1678,182 @@ int orc_mf_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, dou
                 for (int r = 0; r < R; ++r)
                     rhs[d + ldr * r] = dirichlet_vals ? dirichlet_vals[d + ldg * r] : 0.;
             }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Boundary terms and post-processing integrals
+int orc_side_basis_at_qps(int dim, int p, int nq, int side, double* vals, double* ders, double* weights, double* points)
+{
+    if ((dim != 2 && dim != 3) || side < 0 || side >= 2 * dim)
+        return fail(-1, "bad dim / side");
+    const auto rb = makeSideBasis(dim, p, nq, side);
+    std::copy(rb.vals.begin(), rb.vals.end(), vals);
+    std::copy(rb.ders.begin(), rb.ders.end(), ders);
+    std::copy(rb.weights.begin(), rb.weights.end(), weights);
+    std::copy(rb.points.begin(), rb.points.end(), points);
+    return 0;
+}
+int orc_boundary_geometry(int dim, const double* verts, const double* point, int side, double* normal, double* jacobian)
+{
+    double J[9];
+    jacobiMat(dim, verts, point, J);
+    boundaryNormal(dim, side, J, normal);
+    *jacobian = boundaryJacobian(dim, side, J);
+    return 0;
+}
+int orc_residual_params(int residual_id, int* dim, int* n_eq, int* n_fields)
+{
+    const auto* r = getResidual(residual_id);
+    if (!r)
+        return fail(-1, "unknown residual kernel id");
+    *dim      = r->dim;
+    *n_eq     = r->E;
+    *n_fields = r->F;
+    return 0;
+}
+
+// evalElementIntegral / evalElementBoundaryIntegral, post/Integral.hpp:11-52; square != 0: the squared residual
+// (post/NormL2.hpp:21-29).  out[E] is ACCUMULATED.
+int orc_integrate_local(int side, int residual_id, int p, int nq, int square, const double* verts,
+                        const double* node_fields, const double* kparams, double time, double* out)
+{
+    const auto* r = getResidual(residual_id);
+    if (!r)
+        return fail(-1, "unknown residual kernel id");
+    const RefBasis rb = side < 0 ? makeRefBasis(r->dim, p, nq) : makeSideBasis(r->dim, p, nq, side);
+    QpData                qd;
+    std::vector< double > scratch, val(r->E);
+    for (int qi = 0; qi < rb.nqp; ++qi)
+    {
+        KIn in;
+        prepareQp(rb, qi, verts, node_fields, r->F, kparams, time, qd, scratch, side, in);
+        std::fill(val.begin(), val.end(), 0.);
+        r->fun(in, val.data());
+        for (int e = 0; e < r->E; ++e)
+            out[e] += rb.weights[qi] * qd.jac * (square ? val[e] * val[e] : val[e]);
+    }
+    return 0;
+}
+
+// evalLocalIntegral, post/Integral.hpp:54-111: sum over the elements (n_faces < 0) or over the listed element sides.
+// m->fields are the F fields of the residual kernel (SoA).  out[E] is overwritten; no square root is taken.
+int orc_mf_integrate(const orc_mesh* m, int residual_id, int nq, int square, const double* kparams, double time,
+                     int64_t n_faces, const int64_t* face_elem, const uint8_t* face_side, double* out)
+{
+    const auto* r = getResidual(residual_id);
+    if (!r)
+        return fail(-1, "unknown residual kernel id");
+    if (r->dim != m->dim)
+        return fail(-1, "kernel / mesh dimension mismatch");
+    const int             N = ipow(m->p + 1, m->dim), nv = 1 << m->dim, F = r->F;
+    std::vector< double > nf(static_cast< size_t >(N) * F);
+    std::fill(out, out + r->E, 0.);
+    const int64_t count = n_faces < 0 ? m->n_elems : n_faces;
+    for (int64_t i = 0; i < count; ++i)
+    {
+        const int64_t   el    = n_faces < 0 ? i : face_elem[i];
+        const uint32_t* nodes = m->elem_nodes + el * N;
+        for (int n = 0; n < N; ++n)
+            for (int f = 0; f < F; ++f)
+                nf[n * F + f] = m->fields[f * m->n_local_nodes + nodes[n]];
+        if (int rc = orc_integrate_local(n_faces < 0 ? -1 : face_side[i], residual_id, m->p, nq, square,
+                                         m->elem_verts + el * nv * 3, nf.data(), kparams, time, out))
+            return rc;
+    }
+    return 0;
+}
+
+// Matrix-free contribution of a boundary equation kernel on a list of element sides: y += alpha * A_b x with the
+// Dirichlet semantics of the domain apply (gather -> 0, scatter skipped on Dirichlet dofs).  Boundary views are
+// evaluated with the local-element path (algsys/EvaluateLocalOperator.hpp:238-274).
+int orc_bnd_apply(const orc_mesh* m, int kernel_id, const double* kparams, double time, int ncols, int64_t n_faces,
+                  const int64_t* face_elem, const uint8_t* face_side, const double* x, size_t ldx, double* y, size_t ldy,
+                  double alpha)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k || !k->boundary)
+        return fail(-1, "not a boundary kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const int R = ncols, N = ipow(m->p + 1, dim), nv = 1 << dim, Nd = N * U, dpn = m->dofs_per_node;
+    std::vector< double > nf(static_cast< size_t >(N) * std::max(F, 1)), xe(static_cast< size_t >(Nd) * R), ye(static_cast< size_t >(Nd) * R);
+    for (int64_t i = 0; i < n_faces; ++i)
+    {
+        const int64_t   el    = face_elem[i];
+        const uint32_t* nodes = m->elem_nodes + el * N;
+        for (int n = 0; n < N; ++n)
+        {
+            for (int f = 0; f < F; ++f)
+                nf[n * F + f] = m->fields[f * m->n_local_nodes + nodes[n]];
+            for (int u = 0; u < U; ++u)
+            {
+                const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                const bool    dir = m->dirichlet && m->dirichlet[dof];
+                for (int r = 0; r < R; ++r)
+                    xe[(n * U + u) + static_cast< size_t >(Nd) * r] = dir ? 0. : x[dof + ldx * r];
+            }
+        }
+        if (int rc = orc_apply_local_side(face_side[i], kernel_id, m->p, m->nq, R, m->elem_verts + el * nv * 3, nf.data(),
+                                          kparams, time, xe.data(), ye.data()))
+            return rc;
+        for (int n = 0; n < N; ++n)
+            for (int u = 0; u < U; ++u)
+            {
+                const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                if (m->dirichlet && m->dirichlet[dof])
+                    continue;
+                for (int r = 0; r < R; ++r)
+                    y[dof + ldy * r] += alpha * ye[(n * U + u) + static_cast< size_t >(Nd) * r];
+            }
+    }
+    return 0;
+}
+
+// diag / rhs contribution of the boundary term (accumulated; Dirichlet rows are finalised by orc_mf_diag_rhs)
+int orc_bnd_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, double time, int R, int64_t n_faces,
+                     const int64_t* face_elem, const uint8_t* face_side, const double* dirichlet_vals, size_t ldg,
+                     double* diag, double* rhs, size_t ldr)
+{
+    const auto* k = getKernel(kernel_id);
+    if (!k || !k->boundary)
+        return fail(-1, "not a boundary kernel id");
+    const auto [dim, E, U, F] = k->kp;
+    const int N = ipow(m->p + 1, dim), nv = 1 << dim, Nd = N * U, dpn = m->dofs_per_node;
+    std::vector< double > nf(static_cast< size_t >(N) * std::max(F, 1)), ldiag(Nd), lrhs(static_cast< size_t >(Nd) * R), dvals;
+    std::vector< int >    dinds;
+    for (int64_t i = 0; i < n_faces; ++i)
+    {
+        const int64_t   el    = face_elem[i];
+        const uint32_t* nodes = m->elem_nodes + el * N;
+        dinds.clear();
+        for (int n = 0; n < N; ++n)
+        {
+            for (int f = 0; f < F; ++f)
+                nf[n * F + f] = m->fields[f * m->n_local_nodes + nodes[n]];
+            for (int u = 0; u < U; ++u)
+                if (m->dirichlet && m->dirichlet[static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u]])
+                    dinds.push_back(n * U + u);
+        }
+        const int nd = static_cast< int >(dinds.size());
+        dvals.assign(static_cast< size_t >(nd) * R, 0.);
+        for (int j = 0; j < nd; ++j)
+        {
+            const int64_t dof = static_cast< int64_t >(nodes[dinds[j] / U]) * dpn + m->field_inds[dinds[j] % U];
+            for (int r = 0; r < R; ++r)
+                dvals[j + static_cast< size_t >(nd) * r] = dirichlet_vals ? dirichlet_vals[dof + ldg * r] : 0.;
+        }
+        if (int rc = orc_diag_rhs_local_side(face_side[i], kernel_id, m->p, m->nq, R, m->elem_verts + el * nv * 3, nf.data(),
+                                             kparams, time, nd, dinds.data(), dvals.data(), ldiag.data(), lrhs.data()))
+            return rc;
+        for (int n = 0; n < N; ++n)
+            for (int u = 0; u < U; ++u)
+            {
+                const int64_t dof = static_cast< int64_t >(nodes[n]) * dpn + m->field_inds[u];
+                diag[dof] += ldiag[n * U + u];
+                for (int r = 0; r < R; ++r)
+                    rhs[dof + ldr * r] += lrhs[(n * U + u) + static_cast< size_t >(Nd) * r];
+            }
+    }
     return 0;
 }
 } // extern "C"

@@ -32,7 +32,20 @@ enum
     ORC_KERNEL_DIFFUSION3D_VAR = 1, /* tests/Kernels.hpp:84-118, F=1                                                 */
     ORC_KERNEL_DIFFUSION2D     = 2, /* tests/Kernels.hpp:5-24                                                        */
     ORC_KERNEL_DIFFUSION2D_VAR = 3, /* tests/Kernels.hpp:27-52, F=1                                                  */
-    ORC_KERNEL_ADVDIFF3D       = 4  /* synthetic config 5: Diffusion3D rows + sigma, u.grad, F=3     */
+    ORC_KERNEL_ADVDIFF3D       = 4, /* synthetic config 5: Diffusion3D rows + sigma, u.grad, F=3     */
+    /* boundary equation kernels (the input carries the outward normal) */
+    ORC_KERNEL_ADIABATIC2D     = 5, /* tests/Kernels.hpp:120-128: q.n = 0                                            */
+    ORC_KERNEL_ADIABATIC3D     = 6, /* 3-D twin                                                                      */
+    ORC_KERNEL_ROBIN3D         = 7  /* synthetic: q.n + h T = h T_inf, kp = {h, T_inf}                               */
+};
+/* residual kernels for integrals / L2 norms (fields are the kernel's n_fields inputs) */
+enum
+{
+    ORC_RESIDUAL_DIFFUSION3D_ERROR = 0, /* benchmarks/Diffusion3D.hpp:81-103, F = E = 4, kp = {k, s}                 */
+    ORC_RESIDUAL_LINEAR2D_ERROR    = 1, /* tests/Diffusion2D.hpp:84-92 (exact T = x), F = E = 3                     */
+    ORC_RESIDUAL_LINEAR3D_ERROR    = 2, /* 3-D twin, F = E = 4                                                      */
+    ORC_RESIDUAL_UNIT2D            = 3, /* tests/MappingTests.cpp:567-569: integrand 1, F = 0, E = 1                */
+    ORC_RESIDUAL_UNIT3D            = 4
 };
 
 /* dims of a kernel: returns 0 on success */
@@ -120,6 +133,40 @@ int orc_mf_apply(const orc_mesh* m, int kernel_id, const double* kparams, double
 int orc_mf_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, double time, int R,
                     const double* dirichlet_vals, size_t ldg, double* diag, double* rhs, size_t ldr,
                     int64_t e_begin, int64_t e_end, int finalize, int64_t n_owned_dofs, int nthreads);
+
+/* ---- boundary terms and post-processing ---------------------------------------------- */
+/* side < 0: domain.  Sides as mesh/ElementTraits.hpp:84-95: hex 0..5 = z-,z+,y-,y+,x-,x+; quad 0..3 = y-,y+,x-,x+ */
+/* full element basis at the quadrature of one side: vals[nq^(dim-1)][N], ders[.][dim][N], weights, points[.][dim].
+ * basisfun/ReferenceElementBasisAtQuadrature.hpp:21-97, mapping/ReferenceBoundaryToSideMapping.hpp */
+int orc_side_basis_at_qps(int dim, int p, int nq, int side, double* vals, double* ders, double* weights, double* points);
+/* outward unit normal and surface jacobian.  mapping/BoundaryNormal.hpp:8-64, mapping/BoundaryIntegralJacobian.hpp */
+int orc_boundary_geometry(int dim, const double* verts, const double* point, int side, double* normal, double* jacobian);
+/* the local-element functions above on one side of the element with a boundary equation kernel
+ * (algsys/AssembleLocalSystem.hpp:258-281, algsys/EvaluateLocalOperator.hpp:238-274,303-330) */
+int orc_assemble_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                            const double* kparams, double time, double* K, double* F_e);
+int orc_apply_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                         const double* kparams, double time, const double* x, double* y);
+int orc_diag_rhs_local_side(int side, int kernel_id, int p, int nq, int R, const double* verts, const double* node_fields,
+                            const double* kparams, double time, int n_dir, const int* dir_inds, const double* dir_vals,
+                            double* diag, double* rhs);
+int orc_residual_params(int residual_id, int* dim, int* n_eq, int* n_fields);
+/* out[E] += integral over the element (side < 0) or one of its sides of the residual kernel (squared if square != 0).
+ * post/Integral.hpp:11-52, post/NormL2.hpp:21-29.  node_fields [N][F] */
+int orc_integrate_local(int side, int residual_id, int p, int nq, int square, const double* verts,
+                        const double* node_fields, const double* kparams, double time, double* out);
+/* out[E] = sum over all elements (n_faces < 0) or the listed element sides; m->fields = the F fields (SoA).
+ * post/Integral.hpp:54-111 */
+int orc_mf_integrate(const orc_mesh* m, int residual_id, int nq, int square, const double* kparams, double time,
+                     int64_t n_faces, const int64_t* face_elem, const uint8_t* face_side, double* out);
+/* y += alpha * A_b x for a boundary equation kernel on the listed element sides (Dirichlet semantics of orc_mf_apply) */
+int orc_bnd_apply(const orc_mesh* m, int kernel_id, const double* kparams, double time, int ncols, int64_t n_faces,
+                  const int64_t* face_elem, const uint8_t* face_side, const double* x, size_t ldx, double* y, size_t ldy,
+                  double alpha);
+/* diag += diag(A_b), rhs += B_b^T W (f_b - B_b g) on the listed element sides */
+int orc_bnd_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, double time, int R, int64_t n_faces,
+                     const int64_t* face_elem, const uint8_t* face_side, const double* dirichlet_vals, size_t ldg,
+                     double* diag, double* rhs, size_t ldr);
 
 const char* orc_last_error(void);
 

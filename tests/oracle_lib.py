@@ -258,3 +258,132 @@ def mf_diag_rhs(mesh, kid, R=1, dirichlet_vals=None, kparams=None, time=0.0, dia
                                _d(diag), _d(rhs), C.c_size_t(nl), C.c_int64(e_begin), C.c_int64(e_end),
                                int(finalize), C.c_int64(n_owned), int(nthreads)))
     return diag, rhs
+
+
+# ---- boundary terms and post-processing integrals ------------------------------------------
+KERNEL_ADIABATIC2D = 5
+KERNEL_ADIABATIC3D = 6
+KERNEL_ROBIN3D = 7
+RESIDUAL_DIFFUSION3D_ERROR = 0
+RESIDUAL_LINEAR2D_ERROR = 1
+RESIDUAL_LINEAR3D_ERROR = 2
+RESIDUAL_UNIT2D = 3
+RESIDUAL_UNIT3D = 4
+
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def side_basis_at_qps(dim, p, nq, side):
+    N, nqp = (p + 1) ** dim, nq ** (dim - 1)
+    vals, ders = np.zeros((nqp, N)), np.zeros((nqp, dim, N))
+    w, pts = np.zeros(nqp), np.zeros((nqp, dim))
+    _chk(lib().orc_side_basis_at_qps(dim, p, nq, side, _d(vals), _d(ders), _d(w), _d(pts)))
+    return vals, ders, w, pts
+
+
+def boundary_geometry(dim, verts, point, side):
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    point = np.ascontiguousarray(point, dtype=np.float64)
+    nrm, jac = np.zeros(3), C.c_double()
+    _chk(lib().orc_boundary_geometry(dim, _d(verts), _d(point), side, _d(nrm), C.byref(jac)))
+    return nrm[:dim], jac.value
+
+
+def assemble_local_side(side, kid, p, nq, R, verts, node_fields=None, kparams=None, time=0.0):
+    kp, N, verts, nf, kpar = _prep(kid, p, verts, node_fields, kparams)
+    Nd = N * kp["U"]
+    K = np.zeros((Nd, Nd))
+    F = np.zeros((Nd, R), order="F")
+    _chk(lib().orc_assemble_local_side(side, kid, p, nq, R, _d(verts), _d(nf), _d(kpar), C.c_double(time), _d(K), _d(F)))
+    return K, F
+
+
+def apply_local_side(side, kid, p, nq, verts, x, node_fields=None, kparams=None, time=0.0):
+    kp, N, verts, nf, kpar = _prep(kid, p, verts, node_fields, kparams)
+    x = np.asfortranarray(x, dtype=np.float64)
+    y = np.zeros_like(x, order="F")
+    _chk(lib().orc_apply_local_side(side, kid, p, nq, x.shape[1], _d(verts), _d(nf), _d(kpar), C.c_double(time), _d(x),
+                                    _d(y)))
+    return y
+
+
+def diag_rhs_local_side(side, kid, p, nq, R, verts, dir_inds=None, dir_vals=None, node_fields=None, kparams=None,
+                        time=0.0):
+    kp, N, verts, nf, kpar = _prep(kid, p, verts, node_fields, kparams)
+    Nd = N * kp["U"]
+    diag = np.zeros(Nd)
+    rhs = np.zeros((Nd, R), order="F")
+    nd = 0 if dir_inds is None else len(dir_inds)
+    di = None if nd == 0 else np.ascontiguousarray(dir_inds, dtype=np.int32)
+    dv = None if nd == 0 else np.asfortranarray(dir_vals, dtype=np.float64)
+    _chk(lib().orc_diag_rhs_local_side(side, kid, p, nq, R, _d(verts), _d(nf), _d(kpar), C.c_double(time), nd,
+                                       None if di is None else di.ctypes.data_as(_ip), _d(dv), _d(diag), _d(rhs)))
+    return diag, rhs
+
+
+def residual_params(rid):
+    v = [C.c_int() for _ in range(3)]
+    _chk(lib().orc_residual_params(rid, *[C.byref(x) for x in v]))
+    return dict(dim=v[0].value, E=v[1].value, F=v[2].value)
+
+
+def integrate_local(side, rid, p, nq, verts, node_fields, square=False, kparams=None, time=0.0):
+    rp = residual_params(rid)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    nf = None if rp["F"] == 0 else np.ascontiguousarray(node_fields, dtype=np.float64)
+    assert nf is None or nf.shape == ((p + 1) ** rp["dim"], rp["F"])
+    kpar = None if kparams is None else np.ascontiguousarray(kparams, dtype=np.float64)
+    out = np.zeros(rp["E"])
+    _chk(lib().orc_integrate_local(side, rid, p, nq, int(square), _d(verts), _d(nf), _d(kpar), C.c_double(time), _d(out)))
+    return out
+
+
+def _faces(face_elem, face_side):
+    fe = np.ascontiguousarray(face_elem, dtype=np.int64)
+    fs = np.ascontiguousarray(face_side, dtype=np.uint8)
+    assert fe.shape == fs.shape
+    return fe, fs
+
+
+def mf_integrate(mesh, rid, nq, square=False, kparams=None, time=0.0, face_elem=None, face_side=None):
+    """Integral (or integral of the square) of a residual kernel over the mesh / the listed element sides;
+    mesh.fields must hold the kernel's F fields (SoA)."""
+    rp = residual_params(rid)
+    kpar = None if kparams is None else np.ascontiguousarray(kparams, dtype=np.float64)
+    out = np.zeros(rp["E"])
+    if face_elem is None:
+        _chk(lib().orc_mf_integrate(C.byref(mesh.struct), rid, nq, int(square), _d(kpar), C.c_double(time),
+                                    C.c_int64(-1), None, None, _d(out)))
+    else:
+        fe, fs = _faces(face_elem, face_side)
+        _chk(lib().orc_mf_integrate(C.byref(mesh.struct), rid, nq, int(square), _d(kpar), C.c_double(time),
+                                    C.c_int64(len(fe)), fe.ctypes.data_as(_i64p), fs.ctypes.data_as(_u8p), _d(out)))
+    return out
+
+
+def bnd_apply(mesh, kid, face_elem, face_side, x, y, alpha=1.0, kparams=None, time=0.0):
+    """y += alpha * A_b x (in place on the Fortran-ordered y)."""
+    fe, fs = _faces(face_elem, face_side)
+    x = np.asfortranarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1, order="F")
+    assert y.flags.f_contiguous and y.shape == x.shape
+    kpar = None if kparams is None else np.ascontiguousarray(kparams, dtype=np.float64)
+    _chk(lib().orc_bnd_apply(C.byref(mesh.struct), kid, _d(kpar), C.c_double(time), x.shape[1], C.c_int64(len(fe)),
+                             fe.ctypes.data_as(_i64p), fs.ctypes.data_as(_u8p), _d(x), C.c_size_t(x.shape[0]), _d(y),
+                             C.c_size_t(y.shape[0]), C.c_double(alpha)))
+    return y
+
+
+def bnd_diag_rhs(mesh, kid, face_elem, face_side, diag, rhs, dirichlet_vals=None, kparams=None, time=0.0):
+    """diag, rhs accumulated in place."""
+    fe, fs = _faces(face_elem, face_side)
+    nl, R = rhs.shape
+    assert rhs.flags.f_contiguous
+    g = None if dirichlet_vals is None else np.asfortranarray(dirichlet_vals, dtype=np.float64).reshape(nl, R, order="F")
+    kpar = None if kparams is None else np.ascontiguousarray(kparams, dtype=np.float64)
+    _chk(lib().orc_bnd_diag_rhs(C.byref(mesh.struct), kid, _d(kpar), C.c_double(time), R, C.c_int64(len(fe)),
+                                fe.ctypes.data_as(_i64p), fs.ctypes.data_as(_u8p), _d(g), C.c_size_t(nl), _d(diag),
+                                _d(rhs), C.c_size_t(nl)))
+    return diag, rhs
