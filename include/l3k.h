@@ -69,7 +69,17 @@ enum
 {
     L3K_KERNEL_DIFFUSION3D     = 0, /* benchmarks/Diffusion3D.hpp:51-79; params {double k, s}                        */
     L3K_KERNEL_DIFFUSION3D_VAR = 1, /* tests/Kernels.hpp:84-118, n_fields = 1                                          */
-    L3K_KERNEL_ADVDIFF3D       = 4  /* config-5 synthetic; params {double k, sigma, s}, n_fields = 3 */
+    L3K_KERNEL_ADVDIFF3D       = 4, /* config-5 synthetic; params {double k, sigma, s}, n_fields = 3 */
+    /* boundary equation kernels (wrapBoundaryEquationKernel: the input carries the outward normal); l3k_bnd_create */
+    L3K_KERNEL_ADIABATIC3D     = 6, /* 3-D twin of tests/Kernels.hpp:120-128: q.n = 0                                 */
+    L3K_KERNEL_ROBIN3D         = 7  /* synthetic: q.n + h T = h T_inf; params {double h, t_inf}                      */
+};
+/* residual kernels (wrapDomainResidualKernel / wrapBoundaryResidualKernel) for l3k_integrate */
+enum
+{
+    L3K_RESIDUAL_DIFFUSION3D_ERROR = 0, /* benchmarks/Diffusion3D.hpp:81-103; fields (T,qx,qy,qz); params {double k, s} */
+    L3K_RESIDUAL_LINEAR3D_ERROR    = 2, /* 3-D twin of tests/Diffusion2D.hpp:84-92: error against T = x, q = (1,0,0)   */
+    L3K_RESIDUAL_UNIT3D            = 4  /* tests/MappingTests.cpp:567-569: integrand 1                                */
 };
 int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_t* param_bytes);
 /* number of (kernel, order, nq, ncols) device instantiations, and the i-th one: for "is this shape built?" queries */
@@ -152,6 +162,42 @@ int l3k_unpack_add_rows(l3k_ctx* ctx, const double* d_src, int64_t n, const int3
 int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
                     size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg, int finalize);
 
+/* ---- boundary equation kernels on element sides ---------------------------------------------------------------------
+ * assembleProblem(kernel, boundary_ids) with a BoundaryEquationKernel (algsys/MatrixFreeSystem.hpp:58-68): the term
+ * sum over the listed element sides of  int_side B^T B  with the side quadrature, surface jacobian and outward normal
+ * of map::mapBoundary (algsys/EvaluateLocalOperator.hpp:238-274,303-330; mapping/BoundaryNormal.hpp:8-64;
+ * mapping/BoundaryIntegralJacobian.hpp:9-29; basisfun/ReferenceElementBasisAtQuadrature.hpp:57-97).
+ * A side is (element index in the mesh, side): hex sides 0..5 = z-, z+, y-, y+, x-, x+ (mesh/ElementTraits.hpp:84-95).
+ * l3k_mf_attach_boundary registers the term with a system: l3k_mf_apply / l3k_mf_apply_elems / l3k_mf_diag_rhs then
+ * include it, like the reference evaluates every kernel passed to assembleProblem.  `which` as in l3k_mf_apply_elems:
+ * sides of interior elements (0), of border elements (1), all (2).  The term does not own the system or the mesh and
+ * must outlive the systems it is attached to. */
+typedef struct l3k_bnd l3k_bnd;
+int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kparam_blob, size_t kparam_bytes,
+                   const l3k_asmopts* opts, const int* field_inds, int n_rhs, int64_t n_faces, const int64_t* face_elem,
+                   const uint8_t* face_side, l3k_bnd** out);
+int l3k_bnd_destroy(l3k_bnd* bnd);
+int l3k_bnd_set_fields(l3k_bnd* bnd, const double* d_soa, size_t ld);
+int l3k_bnd_set_time(l3k_bnd* bnd, double time);
+/* y += alpha * A_b x  (Dirichlet columns read as 0, Dirichlet rows skipped: same semantics as the element kernels) */
+int l3k_bnd_apply(l3k_bnd* bnd, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, double* d_y,
+                  size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha);
+/* diag += diag(A_b) (d_diag may be NULL), rhs += B_b^T W (f_b - B_b g) */
+int l3k_bnd_diag_rhs(l3k_bnd* bnd, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
+                     size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg);
+int l3k_mf_attach_boundary(l3k_mf* mf, l3k_bnd* bnd);
+
+/* ---- integrals of residual kernels (post-processing) -----------------------------------------------------------------
+ * evalLocalIntegral, post/Integral.hpp:54-111: h_out[n_equations] (HOST) = sum over all elements (n_faces < 0) or over
+ * the listed element sides of the integral of the residual kernel evaluated on the fields d_fields (SoA [F][ld], local
+ * node index); square != 0 integrates the squared components.  computeNormL2 (post/NormL2.hpp:31-62) is
+ * sqrt(all-reduce(l3k_integrate(opts with value_order and derivative_order doubled, square = 1))).  The quadrature
+ * size follows from opts as for the operator kernels.  Results are bitwise reproducible (fixed summation order). */
+int l3k_residual_info(int residual_id, l3k_kparams* params, const char** name, size_t* param_bytes);
+int l3k_integrate(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
+                  const l3k_asmopts* opts, const double* d_fields, size_t ldf, double time, int square, int64_t n_faces,
+                  const int64_t* face_elem, const uint8_t* face_side, double* h_out);
+
 /* ---- LocalAssembly --------------------------------------------------------------------------------------------------
  * assembleLocalSystem for a batch of elements, algsys/AssembleLocalSystem.hpp:234-256: K_e row-major [Nd][Nd],
  * F_e column-major [Nd][n_rhs] per element, elements [first, first+count).  d_K may be NULL (then only the checksum
@@ -187,6 +233,8 @@ typedef struct
     const int32_t*  send_nodes;
     const int64_t*  ghost_offsets;         /* [n_nbrs+1] ghost-node ranges (relative to n_owned_nodes) owned by each
                                               neighbour (import receive / export send); ghosts are sorted by global id */
+    const uint8_t*  elem_boundary;         /* [n_elems] bit s set if side s of the element lies on cube side s: the
+                                              boundary views of makeCubeMesh (mesh/primitives/CubeMesh.hpp:66-138)   */
 } l3k_hostmesh_view;
 int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* out);
 

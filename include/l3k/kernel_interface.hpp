@@ -90,6 +90,20 @@ struct KernelInterface
         FieldVals      field_ders[params.dimension];
         SpaceTimePoint point;
     };
+    // boundary kernels additionally see the outward unit normal (common/KernelInterface.hpp:48-57)
+    struct Normal
+    {
+        double               c[params.dimension];
+        L3K_HD double        operator[](int i) const { return c[i]; }
+        static constexpr int size() { return params.dimension; }
+    };
+    struct BoundaryInput
+    {
+        FieldVals      field_vals;
+        FieldVals      field_ders[params.dimension];
+        SpaceTimePoint point;
+        Normal         normal;
+    };
 };
 
 // common/KernelInterface.hpp:102-119: zero-initialise the result, then invoke the user callable
@@ -113,6 +127,66 @@ template < KernelParams params, typename Kernel >
 constexpr auto wrapDomainEquationKernel(Kernel kernel)
 {
     return DomainEquationKernel< Kernel, params >{kernel};
+}
+
+// Boundary equation kernel: same result type, BoundaryInput (common/KernelInterface.hpp:132-153,185-190)
+template < typename Kernel, KernelParams params >
+struct BoundaryEquationKernel
+{
+    static constexpr KernelParams parameters = params;
+    Kernel                        kernel;
+
+    L3K_HD typename KernelInterface< params >::Result
+    operator()(const typename KernelInterface< params >::BoundaryInput& in) const
+    {
+        typename KernelInterface< params >::Result out{};
+        kernel(in, out);
+        return out;
+    }
+};
+template < KernelParams params, typename Kernel >
+constexpr auto wrapBoundaryEquationKernel(Kernel kernel)
+{
+    return BoundaryEquationKernel< Kernel, params >{kernel};
+}
+
+// Residual kernels (common/KernelInterface.hpp:121-130,155-176,192-204): (in, out) with out = Rhs (n_equations x 1,
+// zero-initialised); the same callable may serve as domain and as boundary residual (tests/Diffusion2D.hpp:84-95).
+template < typename Kernel, KernelParams params >
+struct ResidualDomainKernel
+{
+    static constexpr KernelParams parameters = params;
+    Kernel                        kernel;
+
+    L3K_HD typename KernelInterface< params >::Rhs operator()(const typename KernelInterface< params >::DomainInput& in) const
+    {
+        typename KernelInterface< params >::Rhs out{};
+        kernel(in, out);
+        return out;
+    }
+};
+template < typename Kernel, KernelParams params >
+struct ResidualBoundaryKernel
+{
+    static constexpr KernelParams parameters = params;
+    Kernel                        kernel;
+
+    L3K_HD typename KernelInterface< params >::Rhs operator()(const typename KernelInterface< params >::BoundaryInput& in) const
+    {
+        typename KernelInterface< params >::Rhs out{};
+        kernel(in, out);
+        return out;
+    }
+};
+template < KernelParams params, typename Kernel >
+constexpr auto wrapDomainResidualKernel(Kernel kernel)
+{
+    return ResidualDomainKernel< Kernel, params >{kernel};
+}
+template < KernelParams params, typename Kernel >
+constexpr auto wrapBoundaryResidualKernel(Kernel kernel)
+{
+    return ResidualBoundaryKernel< Kernel, params >{kernel};
 }
 } // namespace l3k
 #endif

@@ -37,7 +37,8 @@ class HostMeshView(C.Structure):
                 ("n_owned_nodes", C.c_int64), ("n_ghost_nodes", C.c_int64), ("global_node_base", C.c_int64),
                 ("n_global_nodes", C.c_int64), ("elem_nodes", c_uint32_p), ("elem_verts", c_double_p),
                 ("node_grid_id", c_int64_p), ("node_boundary", c_uint8_p), ("n_nbrs", C.c_int), ("nbr_rank", c_int_p),
-                ("send_offsets", c_int64_p), ("send_nodes", c_int32_p), ("ghost_offsets", c_int64_p)]
+                ("send_offsets", c_int64_p), ("send_nodes", c_int32_p), ("ghost_offsets", c_int64_p),
+                ("elem_boundary", c_uint8_p)]
 
 
 # every symbol include/l3k.h declares: (name, restype, argtypes)
@@ -73,6 +74,18 @@ SIGNATURES = {
     "l3k_unpack_add_rows": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, C.c_int]),
     "l3k_mf_diag_rhs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, C.c_int]),
     "l3k_local_assemble": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "l3k_bnd_create": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), c_int_p, C.c_int, C.c_int64,
+                                 c_int64_p, c_uint8_p, C.POINTER(_vp)]),
+    "l3k_bnd_destroy": (C.c_int, [_vp]),
+    "l3k_bnd_set_fields": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "l3k_bnd_set_time": (C.c_int, [_vp, C.c_double]),
+    "l3k_bnd_apply": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int,
+                                C.c_double]),
+    "l3k_bnd_diag_rhs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "l3k_mf_attach_boundary": (C.c_int, [_vp, _vp]),
+    "l3k_residual_info": (C.c_int, [C.c_int, C.POINTER(KParams), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
+    "l3k_integrate": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), _vp, C.c_size_t, C.c_double,
+                                C.c_int, C.c_int64, c_int64_p, c_uint8_p, c_double_p]),
     "l3k_cube_partition_create": (C.c_int, [c_int_p, C.c_int, c_int_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     "l3k_hostmesh_destroy": (C.c_int, [_vp]),
     "l3k_hostmesh_view_get": (C.c_int, [_vp, C.POINTER(HostMeshView)]),

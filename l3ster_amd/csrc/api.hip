@@ -97,6 +97,28 @@ __global__ void unpackAddKernel(const double* __restrict__ src, int64_t n, const
             dst[r + ld * c] += src[i + n * c];
     }
 }
+constexpr int reduce_threads = 256;
+// out[v] = sum_b partial[b][v], fixed summation order (one workgroup per component)
+__global__ __launch_bounds__(reduce_threads) void reducePartialsKernel(const double* __restrict__ partial, int64_t n_blocks,
+                                                                         int nv, double* __restrict__ out)
+{
+    __shared__ double scratch[reduce_threads];
+    const int         tid = threadIdx.x, v = blockIdx.x;
+    double            s   = 0.;
+    for (int64_t b = tid; b < n_blocks; b += reduce_threads)
+        s += partial[b * nv + v];
+    scratch[tid] = s;
+    __syncthreads();
+    for (int w = reduce_threads / 2; w > 0; w >>= 1)
+    {
+        if (tid < w)
+            scratch[tid] += scratch[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0)
+        out[v] = scratch[0];
+}
+
 inline unsigned gridFor(int64_t n, int block = 256)
 {
     const int64_t g = (n + block - 1) / block;
@@ -148,8 +170,10 @@ struct l3k_mesh
     int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
     int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
 };
+struct l3k_bnd;
 struct l3k_mf
 {
+    std::vector< l3k_bnd* > boundary_terms; // attached boundary equation kernels (not owned)
     l3k_ctx*            ctx;
     l3k_mesh*           mesh;
     int                 kernel_id, nq, n_rhs;
@@ -171,6 +195,24 @@ struct l3k_mf
     }
 };
 
+// a boundary equation kernel on a list of element sides (assembleProblem(kernel, boundary_ids) of the reference)
+struct l3k_bnd
+{
+    l3k_ctx*              ctx;
+    l3k_mesh*             mesh;
+    int                   kernel_id, nq, n_rhs;
+    l3k_kparams           kp;
+    std::vector< char >   blob;
+    int                   field_inds[l3k::dev::max_unknowns];
+    DevBuf< double >      tables;
+    DevBuf< int64_t >     face_elem; // sides of interior elements first
+    DevBuf< uint8_t >     face_side;
+    int64_t               n_faces = 0, n_interior_faces = 0;
+    const double*         fields = nullptr;
+    size_t                ldf    = 0;
+    double                time   = 0.;
+};
+
 namespace
 {
 struct KernelMeta
@@ -179,6 +221,7 @@ struct KernelMeta
     l3k_kparams kp;
     const char* name;
     size_t      bytes;
+    bool        boundary = false;
 };
 const std::vector< KernelMeta >& kernelMetas()
 {
@@ -189,9 +232,34 @@ const std::vector< KernelMeta >& kernelMetas()
                  name, std::is_empty_v< T > ? size_t{0} : sizeof(T)});
         L3K_FOR_EACH_KERNEL(L3K_X)
 #undef L3K_X
+#define L3K_X(id, T, name)                                                                                             \
+    m.push_back({id, {T::params.dimension, T::params.n_equations, T::params.n_unknowns, T::params.n_fields, T::params.n_rhs}, \
+                 name, std::is_empty_v< T > ? size_t{0} : sizeof(T), true});
+        L3K_FOR_EACH_BOUNDARY_KERNEL(L3K_X)
+#undef L3K_X
         return m;
     }();
     return metas;
+}
+const std::vector< KernelMeta >& residualMetas()
+{
+    static const std::vector< KernelMeta > metas = [] {
+        std::vector< KernelMeta > m;
+#define L3K_X(id, T, name)                                                                                             \
+    m.push_back({id, {T::params.dimension, T::params.n_equations, T::params.n_unknowns, T::params.n_fields, T::params.n_rhs}, \
+                 name, std::is_empty_v< T > ? size_t{0} : sizeof(T)});
+        L3K_FOR_EACH_RESIDUAL_KERNEL(L3K_X)
+#undef L3K_X
+        return m;
+    }();
+    return metas;
+}
+const KernelMeta* findResidual(int id)
+{
+    for (const auto& k : residualMetas())
+        if (k.id == id)
+            return &k;
+    return nullptr;
 }
 const KernelMeta* findKernel(int id)
 {
@@ -265,6 +333,111 @@ const l3k::dev::Instance* instanceFor(const l3k_mf* mf, int ncols)
                  "(l3ster_amd/csrc/user_kernels.hpp) and rebuild",
                  mf->kernel_id, mf->mesh->order, mf->nq, ncols);
     return inst;
+}
+} // namespace
+
+namespace
+{
+int bndArgs(const l3k_bnd* b, int which, int ncols, l3k::dev::ElemArgs& a)
+{
+    const l3k_mesh* m = b->mesh;
+    a                 = {};
+    a.elem_nodes      = m->elem_nodes.ptr;
+    a.elem_verts      = m->elem_verts.ptr;
+    a.dirichlet       = m->dirichlet.ptr;
+    a.tables          = b->tables.ptr;
+    a.fields          = b->fields;
+    a.ldf             = b->ldf;
+    a.n_owned_dofs    = m->nOwnedDofs();
+    a.time            = b->time;
+    a.dofs_per_node   = m->dofs_per_node;
+    a.face_elem       = b->face_elem.ptr;
+    a.face_side       = b->face_side.ptr;
+    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
+        a.field_inds[u] = b->field_inds[u];
+    switch (which)
+    {
+    case 0:
+        a.face_begin = 0;
+        a.face_count = b->n_interior_faces;
+        break;
+    case 1:
+        a.face_begin = b->n_interior_faces;
+        a.face_count = b->n_faces - b->n_interior_faces;
+        break;
+    case 2:
+        a.face_begin = 0;
+        a.face_count = b->n_faces;
+        break;
+    default:
+        setError("which must be 0 (sides of interior elements), 1 (of border elements) or 2 (all)");
+        return -1;
+    }
+    if (b->kp.n_fields > 0 && !b->fields)
+    {
+        setError("boundary kernel reads %d external fields but l3k_bnd_set_fields was not called", b->kp.n_fields);
+        return -1;
+    }
+    if (ncols < 1 || ncols > b->n_rhs)
+    {
+        setError("number of columns (%d) must be in [1, n_rhs = %d]", ncols, b->n_rhs);
+        return -1;
+    }
+    return 0;
+}
+const l3k::dev::BoundaryInstance* bndInstance(const l3k_bnd* b, int ncols)
+{
+    const auto* inst = l3k::dev::findBoundaryInstance(b->kernel_id, b->mesh->order, b->nq, ncols);
+    if (!inst)
+        setError("no device instantiation for boundary kernel %d, order %d, nq %d, ncols %d: add it to "
+                 "L3K_FOR_EACH_BOUNDARY_INSTANCE (l3ster_amd/csrc/user_kernels.hpp) and rebuild",
+                 b->kernel_id, b->mesh->order, b->nq, ncols);
+    return inst;
+}
+int bndApplyImpl(l3k_bnd* b, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, double* d_y,
+                 size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha)
+{
+    l3k::dev::ElemArgs a;
+    if (int rc = bndArgs(b, which, ncols, a))
+        return rc;
+    const l3k_mesh* m = b->mesh;
+    if (ldx < size_t(m->nOwnedDofs()) || ldy < size_t(m->nOwnedDofs()))
+    {
+        setError("leading dimension smaller than the number of owned dofs");
+        return -1;
+    }
+    if (m->n_ghost_nodes > 0 && which != 0 && (!d_xghost || !d_yghost))
+    {
+        setError("mesh has ghost nodes: sides of border elements need the ghost import/export buffers");
+        return -1;
+    }
+    a.x = d_x, a.xg = d_xghost, a.y = d_y, a.yg = d_yghost;
+    a.ldx = ldx, a.ldxg = ldxg, a.ldy = ldy, a.ldyg = ldyg;
+    a.alpha = alpha;
+    const auto* inst = bndInstance(b, ncols);
+    if (!inst)
+        return -4;
+    return inst->apply(a, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream);
+}
+int bndDiagRhsImpl(l3k_bnd* b, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
+                   size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg)
+{
+    l3k::dev::ElemArgs a;
+    if (int rc = bndArgs(b, which, b->n_rhs, a))
+        return rc;
+    if (b->mesh->n_ghost_nodes > 0 && which != 0 && (!d_rhs_ghost || (d_diag && !d_diag_ghost)))
+    {
+        setError("mesh has ghost nodes: sides of border elements need the ghost diag / rhs buffers");
+        return -1;
+    }
+    a.dirichlet_vals = d_dirichlet_vals;
+    a.ldg            = ldg;
+    a.y = d_rhs, a.ldy = ldr, a.yg = d_rhs_ghost, a.ldyg = ldrg;
+    a.diag = d_diag, a.diag_g = d_diag_ghost;
+    const auto* inst = bndInstance(b, b->n_rhs);
+    if (!inst)
+        return -4;
+    return inst->diag_rhs(a, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream);
 }
 } // namespace
 
@@ -523,6 +696,11 @@ int l3k_mf_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpara
         setError("unknown kernel id %d", kernel_id);
         return -1;
     }
+    if (k->boundary)
+    {
+        setError("kernel %s is a boundary equation kernel: use l3k_bnd_create", k->name);
+        return -1;
+    }
     if (k->kp.dimension != mesh->dim)
     {
         setError("kernel dimension %d != mesh dimension %d", k->kp.dimension, mesh->dim);
@@ -676,7 +854,13 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     const auto* inst = instanceFor(mf, ncols);
     if (!inst)
         return -4;
-    return inst->apply(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream);
+    if (int rc = inst->apply(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream))
+        return rc;
+    // boundary equation kernels registered on this system act on the sides of the same element range
+    for (l3k_bnd* b : mf->boundary_terms)
+        if (int rc = bndApplyImpl(b, which, d_x, ldx, d_xghost, ldxg, d_y, ldy, d_yghost, ldyg, ncols, alpha))
+            return rc;
+    return 0;
 }
 
 int l3k_mf_dirichlet_rows(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha)
@@ -771,6 +955,9 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
         return -4;
     if (int rc = inst->diag_rhs(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream))
         return rc;
+    for (l3k_bnd* b : mf->boundary_terms)
+        if (int rc = bndDiagRhsImpl(b, which, d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, d_diag_ghost, d_rhs_ghost, ldrg))
+            return rc;
     if (finalize && mf->mesh->owned_dirichlet_rows.n > 0 && d_diag)
     {
         const auto& rows = mf->mesh->owned_dirichlet_rows;
@@ -849,6 +1036,275 @@ int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, do
         if (int rc = inst->diag_rhs(a, blob, s))
             return rc;
     }
+    return 0;
+}
+// ------------------------------------------------------------------------------------------------ boundary terms
+int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kparam_blob, size_t kparam_bytes,
+                   const l3k_asmopts* opts, const int* field_inds, int n_rhs, int64_t n_faces, const int64_t* face_elem,
+                   const uint8_t* face_side, l3k_bnd** out)
+{
+    if (!ctx || !mesh || !out || n_faces < 0 || (n_faces > 0 && (!face_elem || !face_side)))
+    {
+        setError("l3k_bnd_create: bad argument");
+        return -1;
+    }
+    const auto* k = findKernel(kernel_id);
+    if (!k || !k->boundary)
+    {
+        setError("kernel id %d is not a boundary equation kernel", kernel_id);
+        return -1;
+    }
+    if (k->kp.dimension != mesh->dim)
+    {
+        setError("kernel dimension %d != mesh dimension %d", k->kp.dimension, mesh->dim);
+        return -1;
+    }
+    if (kparam_blob && kparam_bytes != k->bytes)
+    {
+        setError("kernel %s expects a %zu-byte parameter block, got %zu", k->name, k->bytes, kparam_bytes);
+        return -1;
+    }
+    if (n_rhs < 1 || k->kp.n_unknowns > l3k::dev::max_unknowns)
+    {
+        setError("n_rhs must be >= 1 and n_unknowns <= %d", l3k::dev::max_unknowns);
+        return -1;
+    }
+    for (int64_t i = 0; i < n_faces; ++i) // operand shapes must match what the kernel assumes
+        if (face_elem[i] < 0 || face_elem[i] >= mesh->n_elems || face_side[i] >= 6)
+        {
+            setError("side %lld = (element %lld, side %d) is outside the mesh", (long long)i, (long long)face_elem[i],
+                     int(face_side[i]));
+            return -1;
+        }
+    const l3k_asmopts o = opts ? *opts : l3k_asmopts{1, 0, 0};
+    auto              b = std::make_unique< l3k_bnd >();
+    b->ctx = ctx, b->mesh = mesh, b->kernel_id = kernel_id, b->n_rhs = n_rhs, b->kp = k->kp;
+    b->nq = l3k_n_qps1d(mesh->order, o.value_order, o.derivative_order);
+    if (kparam_blob)
+        b->blob.assign(static_cast< const char* >(kparam_blob), static_cast< const char* >(kparam_blob) + kparam_bytes);
+    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
+        b->field_inds[u] = 0;
+    for (int u = 0; u < k->kp.n_unknowns; ++u)
+    {
+        const int fi = field_inds ? field_inds[u] : u;
+        if (fi < 0 || fi >= mesh->dofs_per_node)
+        {
+            setError("field_inds[%d] = %d outside [0, dofs_per_node = %d)", u, fi, mesh->dofs_per_node);
+            return -1;
+        }
+        b->field_inds[u] = fi;
+    }
+    // sides of interior elements first (they need no ghost data, like the interior elements themselves)
+    std::vector< int64_t > fe;
+    std::vector< uint8_t > fs;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        for (int64_t i = 0; i < n_faces; ++i)
+            if ((face_elem[i] >= mesh->n_interior) == (pass == 1))
+            {
+                fe.push_back(face_elem[i]);
+                fs.push_back(face_side[i]);
+            }
+        if (pass == 0)
+            b->n_interior_faces = int64_t(fe.size());
+    }
+    b->n_faces = n_faces;
+    L3K_HIP(hipSetDevice(ctx->device));
+    const auto block = l3k::host::deviceTableBlock(mesh->order, b->nq);
+    if (int rc = b->tables.upload(block.data(), block.size(), ctx->stream))
+        return rc;
+    if (int rc = b->face_elem.upload(fe.data(), fe.size(), ctx->stream))
+        return rc;
+    if (int rc = b->face_side.upload(fs.data(), fs.size(), ctx->stream))
+        return rc;
+    L3K_HIP(hipStreamSynchronize(ctx->stream));
+    *out = b.release();
+    return 0;
+}
+int l3k_bnd_destroy(l3k_bnd* bnd)
+{
+    delete bnd;
+    return 0;
+}
+int l3k_bnd_set_fields(l3k_bnd* bnd, const double* d_soa, size_t ld)
+{
+    if (!bnd)
+    {
+        setError("null bnd");
+        return -1;
+    }
+    if (d_soa && ld < size_t(bnd->mesh->n_owned_nodes + bnd->mesh->n_ghost_nodes))
+    {
+        setError("field leading dimension %zu < number of local nodes", ld);
+        return -1;
+    }
+    bnd->fields = d_soa;
+    bnd->ldf    = ld;
+    return 0;
+}
+int l3k_bnd_set_time(l3k_bnd* bnd, double time)
+{
+    if (!bnd)
+    {
+        setError("null bnd");
+        return -1;
+    }
+    bnd->time = time;
+    return 0;
+}
+int l3k_bnd_apply(l3k_bnd* bnd, int which, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, double* d_y,
+                  size_t ldy, double* d_yghost, size_t ldyg, int ncols, double alpha)
+{
+    if (!bnd || !d_x || !d_y)
+    {
+        setError("l3k_bnd_apply: null argument");
+        return -1;
+    }
+    return bndApplyImpl(bnd, which, d_x, ldx, d_xghost, ldxg, d_y, ldy, d_yghost, ldyg, ncols, alpha);
+}
+int l3k_bnd_diag_rhs(l3k_bnd* bnd, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
+                     size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg)
+{
+    if (!bnd || !d_rhs)
+    {
+        setError("l3k_bnd_diag_rhs: null argument");
+        return -1;
+    }
+    return bndDiagRhsImpl(bnd, which, d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, d_diag_ghost, d_rhs_ghost, ldrg);
+}
+int l3k_mf_attach_boundary(l3k_mf* mf, l3k_bnd* bnd)
+{
+    if (!mf || !bnd)
+    {
+        setError("l3k_mf_attach_boundary: null argument");
+        return -1;
+    }
+    if (bnd->mesh != mf->mesh)
+    {
+        setError("boundary term and system live on different meshes");
+        return -1;
+    }
+    if (bnd->n_rhs != mf->n_rhs)
+    {
+        setError("boundary term has n_rhs = %d, system has %d", bnd->n_rhs, mf->n_rhs);
+        return -1;
+    }
+    mf->boundary_terms.push_back(bnd);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ integrals
+int l3k_residual_info(int residual_id, l3k_kparams* params, const char** name, size_t* param_bytes)
+{
+    const auto* k = findResidual(residual_id);
+    if (!k)
+    {
+        setError("unknown residual kernel id %d", residual_id);
+        return -1;
+    }
+    if (params)
+        *params = k->kp;
+    if (name)
+        *name = k->name;
+    if (param_bytes)
+        *param_bytes = k->bytes;
+    return 0;
+}
+int l3k_integrate(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
+                  const l3k_asmopts* opts, const double* d_fields, size_t ldf, double time, int square, int64_t n_faces,
+                  const int64_t* face_elem, const uint8_t* face_side, double* h_out)
+{
+    if (!ctx || !mesh || !h_out || (n_faces > 0 && (!face_elem || !face_side)))
+    {
+        setError("l3k_integrate: bad argument");
+        return -1;
+    }
+    const auto* k = findResidual(residual_id);
+    if (!k)
+    {
+        setError("unknown residual kernel id %d", residual_id);
+        return -1;
+    }
+    if (k->kp.dimension != mesh->dim)
+    {
+        setError("kernel dimension %d != mesh dimension %d", k->kp.dimension, mesh->dim);
+        return -1;
+    }
+    if (kparam_blob && kparam_bytes != k->bytes)
+    {
+        setError("kernel %s expects a %zu-byte parameter block, got %zu", k->name, k->bytes, kparam_bytes);
+        return -1;
+    }
+    if (k->kp.n_fields > 0 && (!d_fields || ldf < size_t(mesh->n_owned_nodes + mesh->n_ghost_nodes)))
+    {
+        setError("kernel %s reads %d fields: pass them as SoA with ld >= number of local nodes", k->name, k->kp.n_fields);
+        return -1;
+    }
+    const bool side = n_faces >= 0;
+    for (int64_t i = 0; i < n_faces; ++i)
+        if (face_elem[i] < 0 || face_elem[i] >= mesh->n_elems || face_side[i] >= 6)
+        {
+            setError("side %lld = (element %lld, side %d) is outside the mesh", (long long)i, (long long)face_elem[i],
+                     int(face_side[i]));
+            return -1;
+        }
+    const int E = k->kp.n_equations;
+    for (int i = 0; i < E; ++i)
+        h_out[i] = 0.;
+    const int64_t count = side ? n_faces : mesh->n_elems;
+    if (count == 0)
+        return 0;
+    const l3k_asmopts o  = opts ? *opts : l3k_asmopts{1, 0, 0};
+    const int         nq = l3k_n_qps1d(mesh->order, o.value_order, o.derivative_order);
+    if (nq < mesh->order + 1)
+    {
+        setError("nq = %d < p+1 = %d: the collocation-derivative device algorithm needs nq >= p+1", nq, mesh->order + 1);
+        return -1;
+    }
+    const auto* inst = l3k::dev::findIntegralInstance(residual_id, mesh->order, nq);
+    if (!inst)
+    {
+        setError("no device instantiation for residual kernel %d, order %d, nq %d: add it to "
+                 "L3K_FOR_EACH_RESIDUAL_INSTANCE (l3ster_amd/csrc/user_kernels.hpp) and rebuild",
+                 residual_id, mesh->order, nq);
+        return -4;
+    }
+    L3K_HIP(hipSetDevice(ctx->device));
+    hipStream_t        s = ctx->stream;
+    DevBuf< double >   tables, partial;
+    DevBuf< int64_t >  fe;
+    DevBuf< uint8_t >  fs;
+    const auto         block = l3k::host::deviceTableBlock(mesh->order, nq);
+    if (int rc = tables.upload(block.data(), block.size(), s))
+        return rc;
+    if (side)
+    {
+        if (int rc = fe.upload(face_elem, size_t(n_faces), s))
+            return rc;
+        if (int rc = fs.upload(face_side, size_t(n_faces), s))
+            return rc;
+    }
+    partial.n = size_t(count + 1) * E; // [count][E] partial sums + [E] result
+    L3K_HIP(hipMalloc(reinterpret_cast< void** >(&partial.ptr), partial.n * sizeof(double)));
+    l3k::dev::ElemArgs a{};
+    a.elem_nodes = mesh->elem_nodes.ptr;
+    a.elem_verts = mesh->elem_verts.ptr;
+    a.tables     = tables.ptr;
+    a.fields     = d_fields;
+    a.ldf        = ldf;
+    a.time       = time;
+    a.elem_begin = 0, a.elem_count = mesh->n_elems;
+    a.face_elem = fe.ptr, a.face_side = fs.ptr, a.face_begin = 0, a.face_count = side ? n_faces : 0;
+    a.partial = partial.ptr;
+    a.square  = square;
+    if (int rc = (side ? inst->boundary : inst->domain)(a, kparam_blob, s))
+        return rc;
+    double* d_out = partial.ptr + size_t(count) * E;
+    hipLaunchKernelGGL(reducePartialsKernel, dim3(E), dim3(reduce_threads), 0, s, partial.ptr, count, E,
+                       d_out);
+    L3K_HIP(hipGetLastError());
+    L3K_HIP(hipMemcpyAsync(h_out, d_out, sizeof(double) * E, hipMemcpyDeviceToHost, s));
+    L3K_HIP(hipStreamSynchronize(s));
     return 0;
 }
 } // extern "C"

@@ -36,7 +36,8 @@ struct TableLayout
     constexpr int offII() const { return offEoCt() + 2 * hq() * hq(); }   // I*I, I*D, D*D elementwise, n x nq each
     constexpr int offID() const { return offII() + n * nq; }
     constexpr int offDD() const { return offID() + n * nq; }
-    constexpr int size() const { return offDD() + n * nq; }
+    constexpr int offE() const { return offDD() + n * nq; } // phi_k'(-1) [n] | phi_k'(+1) [n] (boundary kernels)
+    constexpr int size() const { return offE() + 2 * n; }
 };
 
 // Everything an element kernel needs; passed by value as the kernel argument (scalar loads).
@@ -76,6 +77,12 @@ struct ElemArgs
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS); 0 in production
+    // boundary terms / integrals: element sides [face_begin, face_begin + face_count) of the list (device arrays)
+    const int64_t* face_elem;
+    const uint8_t* face_side;
+    int64_t        face_begin, face_count;
+    double*        partial; // integrals: [n_blocks][E] per-block partial sums
+    int            square;  // integrate the squared residual (L2 norm)
 };
 
 using LaunchFn = int (*)(const ElemArgs&, const void* kparam_blob, hipStream_t stream);
@@ -89,6 +96,24 @@ struct Instance
     size_t   assemble_ws_doubles; // workspace doubles per element for `assemble`
 };
 
+// boundary equation kernel on element sides (device/boundary.hpp)
+struct BoundaryInstance
+{
+    int      kernel_id, order, nq, ncols;
+    LaunchFn apply;    // y += alpha * A_b x
+    LaunchFn diag_rhs; // diag += diag(A_b), rhs += B_b^T W (f_b - B_b g)
+};
+// residual kernel integral (device/integral.hpp); `blocks` = number of partial sums the launch writes
+struct IntegralInstance
+{
+    int      residual_id, order, nq;
+    LaunchFn domain, boundary;
+};
+void                    registerBoundaryInstance(const BoundaryInstance& inst);
+const BoundaryInstance* findBoundaryInstance(int kernel_id, int order, int nq, int ncols);
+void                    registerIntegralInstance(const IntegralInstance& inst);
+const IntegralInstance* findIntegralInstance(int residual_id, int order, int nq);
+
 void            registerInstance(const Instance& inst);
 const Instance* findInstance(int kernel_id, int order, int nq, int ncols);
 int             instanceCount();
@@ -96,6 +121,8 @@ const Instance* instanceAt(int i);
 
 template < typename K >
 struct KernelId;
+template < typename K >
+struct ResidualId;
 
 void setError(const char* fmt, ...);
 } // namespace l3k::dev

@@ -8,6 +8,8 @@
 #include "sumfact_fast.hpp"
 #include "diag.hpp"
 #include "assemble.hpp"
+#include "boundary.hpp"
+#include "integral.hpp"
 
 namespace l3k::dev
 {
@@ -18,6 +20,15 @@ namespace l3k::dev
         static constexpr int value = id;                                                                               \
     };
 L3K_FOR_EACH_KERNEL(L3K_X)
+L3K_FOR_EACH_BOUNDARY_KERNEL(L3K_X)
+#undef L3K_X
+#define L3K_X(id, T, name)                                                                                             \
+    template <>                                                                                                        \
+    struct ResidualId< T >                                                                                             \
+    {                                                                                                                  \
+        static constexpr int value = id;                                                                               \
+    };
+L3K_FOR_EACH_RESIDUAL_KERNEL(L3K_X)
 #undef L3K_X
 } // namespace l3k::dev
 
@@ -50,5 +61,31 @@ constexpr LaunchFn selectApply()
                                           ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >()});             \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
+    }
+#define L3K_INSTANTIATE_BOUNDARY(T, P, NQ, R)                                                                          \
+    namespace                                                                                                          \
+    {                                                                                                                  \
+    const struct L3K_CAT(BRegistrar_, __LINE__)                                                                        \
+    {                                                                                                                  \
+        L3K_CAT(BRegistrar_, __LINE__)()                                                                               \
+        {                                                                                                              \
+            ::l3k::dev::registerBoundaryInstance({::l3k::dev::KernelId< T >::value, P, NQ, R,                          \
+                                                  &::l3k::dev::launchFace< T, P, NQ, R, false >,                       \
+                                                  &::l3k::dev::launchFace< T, P, NQ, R, true >});                      \
+        }                                                                                                              \
+    } L3K_CAT(bregistrar_, __LINE__);                                                                                  \
+    }
+#define L3K_INSTANTIATE_RESIDUAL(T, P, NQ)                                                                             \
+    namespace                                                                                                          \
+    {                                                                                                                  \
+    const struct L3K_CAT(RRegistrar_, __LINE__)                                                                        \
+    {                                                                                                                  \
+        L3K_CAT(RRegistrar_, __LINE__)()                                                                               \
+        {                                                                                                              \
+            ::l3k::dev::registerIntegralInstance({::l3k::dev::ResidualId< T >::value, P, NQ,                           \
+                                                  &::l3k::dev::launchIntegral< T, P, NQ, false >,                      \
+                                                  &::l3k::dev::launchIntegral< T, P, NQ, true >});                     \
+        }                                                                                                              \
+    } L3K_CAT(rregistrar_, __LINE__);                                                                                  \
     }
 #endif

@@ -210,6 +210,7 @@ struct l3k_hostmesh
     std::vector< double >   elem_verts;
     std::vector< i64 >      node_grid_id;
     std::vector< uint8_t >  node_boundary;
+    std::vector< uint8_t >  elem_boundary;
     std::vector< int >      nbr_rank;
     std::vector< i64 >      send_offsets, ghost_offsets;
     std::vector< int32_t >  send_nodes;
@@ -328,6 +329,7 @@ extern "C" int l3k_cube_partition_create(const int ne[3], int order, const int p
     hm->elem_verts.resize(size_t(me.n_elems) * 24);
     hm->node_grid_id.assign(n_local, -1);
     hm->node_boundary.assign(n_local, 0);
+    hm->elem_boundary.assign(size_t(me.n_elems), 0);
     const double h[3]  = {1. / ne[0], 1. / ne[1], 1. / ne[2]};
     const double hmin  = std::min({h[0], h[1], h[2]});
     const double twopi = 6.283185307179586476925286766559;
@@ -337,6 +339,10 @@ extern "C" int l3k_cube_partition_create(const int ne[3], int order, const int p
         const int     E[3] = {me.eb[0] + lex % me.ext[0], me.eb[1] + (lex / me.ext[0]) % me.ext[1],
                               me.eb[2] + lex / (me.ext[0] * me.ext[1])};
         uint32_t*     en   = hm->elem_nodes.data() + size_t(k) * N;
+        // element sides on the cube boundary (the BoundaryViews of makeCubeMesh, mesh/primitives/CubeMesh.hpp:66-138)
+        hm->elem_boundary[k] = static_cast< uint8_t >((E[2] == 0) | ((E[2] == ne[2] - 1) << 1) | ((E[1] == 0) << 2) |
+                                                      ((E[1] == ne[1] - 1) << 3) | ((E[0] == 0) << 4) |
+                                                      ((E[0] == ne[0] - 1) << 5));
         for (int i = 0; i < N; ++i)
         {
             const i64 g[3] = {i64(p) * E[0] + i % n, i64(p) * E[1] + (i / n) % n, i64(p) * E[2] + i / (n * n)};
@@ -480,6 +486,7 @@ extern "C" int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* 
     v->elem_verts       = hm->elem_verts.data();
     v->node_grid_id     = hm->node_grid_id.data();
     v->node_boundary    = hm->node_boundary.data();
+    v->elem_boundary    = hm->elem_boundary.data();
     v->n_nbrs           = static_cast< int >(hm->nbr_rank.size());
     v->nbr_rank         = hm->nbr_rank.data();
     v->send_offsets     = hm->send_offsets.data();

@@ -16,7 +16,40 @@ std::vector< Instance >& table()
     return t;
 }
 thread_local std::string g_error;
+std::vector< BoundaryInstance >& boundaryTable()
+{
+    static std::vector< BoundaryInstance > t;
+    return t;
+}
+std::vector< IntegralInstance >& integralTable()
+{
+    static std::vector< IntegralInstance > t;
+    return t;
+}
 } // namespace
+
+void registerBoundaryInstance(const BoundaryInstance& inst)
+{
+    boundaryTable().push_back(inst);
+}
+const BoundaryInstance* findBoundaryInstance(int kernel_id, int order, int nq, int ncols)
+{
+    for (const auto& i : boundaryTable())
+        if (i.kernel_id == kernel_id && i.order == order && i.nq == nq && i.ncols == ncols)
+            return &i;
+    return nullptr;
+}
+void registerIntegralInstance(const IntegralInstance& inst)
+{
+    integralTable().push_back(inst);
+}
+const IntegralInstance* findIntegralInstance(int residual_id, int order, int nq)
+{
+    for (const auto& i : integralTable())
+        if (i.residual_id == residual_id && i.order == order && i.nq == nq)
+            return &i;
+    return nullptr;
+}
 
 void registerInstance(const Instance& inst)
 {

@@ -209,6 +209,13 @@ std::vector< double > deviceTableBlock(int p, int nq)
     for (int which = 0; which < 3; ++which)
         for (size_t i = 0; i < I.size(); ++i)
             out.push_back(which == 0 ? I[i] * I[i] : (which == 1 ? I[i] * D[i] : D[i] * D[i]));
+    // derivative of the basis at the two ends of the reference interval (normal derivative on an element side)
+    std::vector< double > v(n), d(n);
+    for (double x : {-1., 1.})
+    {
+        lagrange(gll, x, v.data(), d.data());
+        out.insert(out.end(), d.begin(), d.end());
+    }
     return out;
 }
 } // namespace l3k::host

@@ -120,6 +120,89 @@ struct AdvDiff3D
         Ay(6, 1) = -1.;
     }
 };
+
+// ---- boundary equation kernels: the input additionally carries the outward unit normal ----------------------------
+// 3-D twin of tests/Kernels.hpp:120-128 (adiabatic wall of the first-order diffusion system): q . n = 0
+struct Adiabatic3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1, .n_unknowns = 4};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [vals, ders, point, normal] = in;
+        auto& [operators, rhs]                  = out;
+        auto& [A0, A1, A2, A3]                  = operators;
+        A0(0, 1) = normal[0];
+        A0(0, 2) = normal[1];
+        A0(0, 3) = normal[2];
+    }
+};
+// Robin condition q . n + h T = h T_inf (synthetic: A0 on the primary unknown and a non-zero boundary rhs)
+struct Robin3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1, .n_unknowns = 4};
+    double                        h = 1., t_inf = 0.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [vals, ders, point, normal] = in;
+        auto& [operators, rhs]                  = out;
+        auto& [A0, A1, A2, A3]                  = operators;
+        A0(0, 0) = h;
+        A0(0, 1) = normal[0];
+        A0(0, 2) = normal[1];
+        A0(0, 3) = normal[2];
+        rhs[0]   = h * t_inf;
+    }
+};
+
+// ---- residual kernels (integrals, L2 norms): out[n_equations] from the interpolated fields ------------------------
+// benchmarks/Diffusion3D.hpp:81-103: residuals of the first-order diffusion system for the fields (T, qx, qy, qz)
+struct Diffusion3DError
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 4, .n_fields = 4};
+    double                        k = 1., s = 1.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& error) const
+    {
+        const auto& vals                     = in.field_vals;
+        const auto& ders                     = in.field_ders;
+        const auto& [x_ders, y_ders, z_ders] = ders;
+        error[0] = k * (x_ders[1] + y_ders[2] + z_ders[3]) + s;
+        error[1] = x_ders[0] - vals[1];
+        error[2] = y_ders[0] - vals[2];
+        error[3] = z_ders[0] - vals[3];
+    }
+};
+// 3-D twin of tests/Diffusion2D.hpp:84-92: error against the exact solution T = x, q = (1, 0, 0)
+struct Linear3DError
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 4, .n_fields = 4};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& error) const
+    {
+        const auto& vals = in.field_vals;
+        error[0]         = vals[0] - in.point.space.x();
+        error[1]         = vals[1] - 1.;
+        error[2]         = vals[2];
+        error[3]         = vals[3];
+    }
+};
+// tests/MappingTests.cpp:567-569: integrand 1 (volume / area)
+struct Unit3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In&, Out& out) const
+    {
+        out[0] = 1.;
+    }
+};
 } // namespace l3k::kernels
 
 // id, functor type, name
@@ -127,6 +210,17 @@ struct AdvDiff3D
     X(0, ::l3k::kernels::Diffusion3D, "diffusion3d")                                                                   \
     X(1, ::l3k::kernels::Diffusion3DVar, "diffusion3d_var")                                                            \
     X(4, ::l3k::kernels::AdvDiff3D, "advdiff3d")
+
+// boundary equation kernels (ids continue the numbering above; 5 is the 2-D adiabatic kernel of the CPU oracle)
+#define L3K_FOR_EACH_BOUNDARY_KERNEL(X)                                                                                \
+    X(6, ::l3k::kernels::Adiabatic3D, "adiabatic3d")                                                                   \
+    X(7, ::l3k::kernels::Robin3D, "robin3d")
+
+// residual kernels (own id space; 1 and 3 are the 2-D kernels of the CPU oracle)
+#define L3K_FOR_EACH_RESIDUAL_KERNEL(X)                                                                                \
+    X(0, ::l3k::kernels::Diffusion3DError, "diffusion3d_error")                                                        \
+    X(2, ::l3k::kernels::Linear3DError, "linear3d_error")                                                              \
+    X(4, ::l3k::kernels::Unit3D, "unit3d")
 
 // Shapes instantiated on the device: (functor, order p, quadrature points per direction nq, columns R).
 // nq = value_order*p + derivative_order*(p-1) + 1 (algsys/AssembleLocalSystem.hpp:32-35).
@@ -146,5 +240,26 @@ struct AdvDiff3D
     X(::l3k::kernels::AdvDiff3D, 2, 3, 1)                                                                              \
     X(::l3k::kernels::AdvDiff3D, 2, 3, 2)                                                                              \
     X(::l3k::kernels::AdvDiff3D, 4, 5, 1)
+
+#define L3K_FOR_EACH_BOUNDARY_INSTANCE(X)                                                                              \
+    X(::l3k::kernels::Adiabatic3D, 2, 3, 1)                                                                            \
+    X(::l3k::kernels::Adiabatic3D, 4, 5, 1)                                                                            \
+    X(::l3k::kernels::Adiabatic3D, 6, 7, 1)                                                                            \
+    X(::l3k::kernels::Robin3D, 2, 3, 1)                                                                                \
+    X(::l3k::kernels::Robin3D, 2, 3, 2)                                                                                \
+    X(::l3k::kernels::Robin3D, 3, 7, 1)                                                                                \
+    X(::l3k::kernels::Robin3D, 4, 5, 1)
+
+// (functor, order p, nq); computeNormL2 doubles the quadrature orders: nq = 2p+1 for the default options
+#define L3K_FOR_EACH_RESIDUAL_INSTANCE(X)                                                                              \
+    X(::l3k::kernels::Diffusion3DError, 2, 5)                                                                          \
+    X(::l3k::kernels::Diffusion3DError, 4, 9)                                                                          \
+    X(::l3k::kernels::Diffusion3DError, 6, 13)                                                                         \
+    X(::l3k::kernels::Diffusion3DError, 6, 7)                                                                          \
+    X(::l3k::kernels::Linear3DError, 2, 5)                                                                             \
+    X(::l3k::kernels::Linear3DError, 4, 9)                                                                             \
+    X(::l3k::kernels::Unit3D, 1, 6)                                                                                    \
+    X(::l3k::kernels::Unit3D, 2, 3)                                                                                    \
+    X(::l3k::kernels::Unit3D, 2, 5)
 
 #endif

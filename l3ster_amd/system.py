@@ -19,6 +19,11 @@ from .capi import L3KError, check
 KERNEL_DIFFUSION3D = 0
 KERNEL_DIFFUSION3D_VAR = 1
 KERNEL_ADVDIFF3D = 4
+KERNEL_ADIABATIC3D = 6  # boundary equation kernels
+KERNEL_ROBIN3D = 7
+RESIDUAL_DIFFUSION3D_ERROR = 0
+RESIDUAL_LINEAR3D_ERROR = 2
+RESIDUAL_UNIT3D = 4
 
 
 # ------------------------------------------------------------------------------------------------------- tables
@@ -57,6 +62,13 @@ def kernel_info(kernel_id):
                 name=name.value.decode(), param_bytes=nbytes.value)
 
 
+def residual_info(residual_id):
+    kp, name, nbytes = capi.KParams(), C.c_char_p(), C.c_size_t()
+    check(capi.load().l3k_residual_info(residual_id, C.byref(kp), C.byref(name), C.byref(nbytes)))
+    return dict(dimension=kp.dimension, n_equations=kp.n_equations, n_fields=kp.n_fields, name=name.value.decode(),
+                param_bytes=nbytes.value)
+
+
 def instances():
     lib = capi.load()
     out = []
@@ -93,6 +105,7 @@ class CubePartition:
             nl = v.n_owned_nodes + v.n_ghost_nodes
             self.node_grid_id = as_np(v.node_grid_id, (nl,))
             self.node_boundary = as_np(v.node_boundary, (nl,))
+            self.elem_boundary = as_np(v.elem_boundary, (v.n_elems,))
             nn = v.n_nbrs
             self.nbr_rank = [v.nbr_rank[i] for i in range(nn)]
             so = [v.send_offsets[i] for i in range(nn + 1)]
@@ -118,6 +131,32 @@ class CubePartition:
         for u in unknowns:
             mask[on, u] = 1
         return mask.reshape(-1)
+
+    def boundary_sides(self, sides=range(6)):
+        """(element index, side) of this rank's element sides on the listed cube sides: the BoundaryViews of
+        makeCubeMesh (mesh/primitives/CubeMesh.hpp:66-138).  Returns (int64[n], uint8[n])."""
+        fe, fs = [], []
+        for s in sides:
+            e = np.nonzero(self.elem_boundary & (1 << s))[0]
+            fe.append(e.astype(np.int64))
+            fs.append(np.full(e.size, s, dtype=np.uint8))
+        if not fe:
+            return np.zeros(0, np.int64), np.zeros(0, np.uint8)
+        return np.concatenate(fe), np.concatenate(fs)
+
+    def node_coords(self):
+        """Physical location of every local node (mesh/NodePhysicalLocation.hpp: tri-linear map of the element vertices
+        at the GLL reference positions).  Returns float64 [n_local_nodes, 3]."""
+        g = gll_nodes(self.order + 1)
+        l = np.stack([(1 - g) / 2, (1 + g) / 2], axis=1)  # [n][2] linear shape functions at the GLL points
+        n = self.order + 1
+        # shape[(ix,iy,iz) lexicographic, v = i + 2j + 4k]
+        shape = np.einsum("xi,yj,zk->zyxkji", l, l, l).reshape(n ** 3, 8)
+        coords = np.zeros((self.n_local_nodes, 3))
+        for e0 in range(0, self.n_elems, 65536):
+            ev = self.elem_verts[e0:e0 + 65536]
+            coords[self.elem_nodes[e0:e0 + 65536].reshape(-1)] = np.einsum("nv,evs->ens", shape, ev).reshape(-1, 3)
+        return coords
 
     def synthetic_vector(self, dofs_per_node, seed=42, ncols=1):
         """x ~ U(-1,1) as a function of (partition-independent grid node id, dof, column): every partition of the same
@@ -210,6 +249,113 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _blob(kernel_params):
+    if kernel_params is None:
+        return None, 0, None
+    arr = np.ascontiguousarray(kernel_params, dtype=np.float64)
+    return arr.ctypes.data_as(C.c_void_p), arr.nbytes, arr
+
+
+def _sides(face_elem, face_side):
+    fe = np.ascontiguousarray(face_elem, dtype=np.int64)
+    fs = np.ascontiguousarray(face_side, dtype=np.uint8)
+    if fe.shape != fs.shape or fe.ndim != 1:
+        raise L3KError("face_elem and face_side must be 1-D arrays of the same length")
+    return fe, fs
+
+
+class BoundaryTerm:
+    """A boundary equation kernel on a list of element sides: assembleProblem(kernel, boundary_ids) of the reference
+    (algsys/MatrixFreeSystem.hpp:58-68).  Attach it to a MatrixFreeSystem, or use apply / diag_rhs directly."""
+
+    def __init__(self, mesh, kernel_id, face_elem, face_side, kernel_params=None, asm_opts=(1, 0, 0), field_inds=None,
+                 n_rhs=1):
+        self.mesh, self.ctx, self.kernel_id, self.n_rhs = mesh, mesh.ctx, kernel_id, n_rhs
+        self.info = kernel_info(kernel_id)
+        blob, nbytes, self._keep = _blob(kernel_params)
+        opts = capi.AsmOpts(*asm_opts)
+        fi = None if field_inds is None else (C.c_int * len(field_inds))(*field_inds)
+        fe, fs = _sides(face_elem, face_side)
+        self.n_faces = fe.size
+        self._h = C.c_void_p()
+        check(capi.load().l3k_bnd_create(self.ctx._h, mesh._h, kernel_id, blob, nbytes, C.byref(opts), fi, n_rhs, fe.size,
+                                         fe.ctypes.data_as(capi.c_int64_p), fs.ctypes.data_as(capi.c_uint8_p),
+                                         C.byref(self._h)))
+        self._fields = None
+
+    def __del__(self):
+        if getattr(self, "_h", None) and capi is not None:
+            capi.load().l3k_bnd_destroy(self._h)
+            self._h = None
+
+    def set_fields(self, fields):
+        if fields is not None and (fields.dim() != 2 or not fields.is_contiguous()):
+            raise L3KError("fields must be a contiguous (n_fields, n_local_nodes) tensor")
+        self._fields = fields
+        check(capi.load().l3k_bnd_set_fields(self._h, _ptr(fields), 0 if fields is None else fields.shape[1]))
+
+    def set_time(self, t):
+        check(capi.load().l3k_bnd_set_time(self._h, float(t)))
+
+    def apply(self, X, Y, alpha=1.0, which=2, XG=None, YG=None):
+        """Y += alpha * A_b X"""
+        nc, ldx = MatrixFreeSystem._cols(X)
+        _, ldy = MatrixFreeSystem._cols(Y)
+        ldxg = XG.shape[1] if XG is not None else 0
+        ldyg = YG.shape[1] if YG is not None else 0
+        check(capi.load().l3k_bnd_apply(self._h, which, _ptr(X), ldx, _ptr(XG), ldxg, _ptr(Y), ldy, _ptr(YG), ldyg, nc,
+                                        alpha))
+        return Y
+
+    def diag_rhs(self, diag, rhs, dirichlet_vals=None, which=2, diag_ghost=None, rhs_ghost=None):
+        """diag += diag(A_b), rhs += B_b^T W (f_b - B_b g) (accumulating; no Dirichlet finalisation)"""
+        g = dirichlet_vals
+        ldg = 0 if g is None else g.shape[1]
+        ldrg = 0 if rhs_ghost is None else rhs_ghost.shape[1]
+        check(capi.load().l3k_bnd_diag_rhs(self._h, which, _ptr(g), ldg, _ptr(diag), _ptr(rhs), rhs.shape[1],
+                                           _ptr(diag_ghost), _ptr(rhs_ghost), ldrg))
+        return diag, rhs
+
+
+def integrate(mesh, residual_id, fields=None, kernel_params=None, asm_opts=(1, 0, 0), time=0.0, square=False,
+              face_elem=None, face_side=None):
+    """evalLocalIntegral (post/Integral.hpp:54-111): this rank's integral of a residual kernel over all elements, or over
+    the listed element sides.  fields: contiguous (n_fields, n_local_nodes) device tensor.  Returns a numpy array
+    [n_equations]; multi-rank callers all-reduce it (computeIntegral :113-128)."""
+    info = residual_info(residual_id)
+    blob, nbytes, keep = _blob(kernel_params)
+    opts = capi.AsmOpts(*asm_opts)
+    if fields is not None and (fields.dim() != 2 or not fields.is_contiguous()):
+        raise L3KError("fields must be a contiguous (n_fields, n_local_nodes) tensor")
+    out = np.zeros(info["n_equations"])
+    if face_elem is None:
+        nf, fe_p, fs_p = -1, None, None
+    else:
+        fe, fs = _sides(face_elem, face_side)
+        nf, fe_p, fs_p = fe.size, fe.ctypes.data_as(capi.c_int64_p), fs.ctypes.data_as(capi.c_uint8_p)
+    check(capi.load().l3k_integrate(mesh.ctx._h, mesh._h, residual_id, blob, nbytes, C.byref(opts), _ptr(fields),
+                                    0 if fields is None else fields.shape[1], float(time), int(square), nf, fe_p, fs_p,
+                                    out.ctypes.data_as(capi.c_double_p)))
+    return out
+
+
+def norm_l2(mesh, residual_id, fields=None, kernel_params=None, asm_opts=(1, 0, 0), time=0.0, face_elem=None,
+            face_side=None, group=None):
+    """computeNormL2 (post/NormL2.hpp:31-62): sqrt of the integral of the squared residual with doubled quadrature
+    orders; all-reduced over `group` when torch.distributed is initialised."""
+    doubled = (2 * asm_opts[0], 2 * asm_opts[1], asm_opts[2])
+    sq = integrate(mesh, residual_id, fields, kernel_params, doubled, time, True, face_elem, face_side)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        import torch
+        t = torch.from_numpy(sq)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=group)
+        sq = t.cpu().numpy()
+    return np.sqrt(sq)
+
+
 class MatrixFreeSystem:
     """algsys::MatrixFreeSystem for one rank: kernel + mesh -> operator.  apply() is Operator::apply
     (Y <- alpha*A*X + beta*Y, algsys/MatrixFreeSystem.hpp:34-41,1038)."""
@@ -230,11 +376,17 @@ class MatrixFreeSystem:
         check(capi.load().l3k_mf_create(self.ctx._h, mesh._h, kernel_id, blob, nbytes, C.byref(opts), fi, n_rhs,
                                         C.byref(self._h)))
         self._fields = None
+        self._boundary_terms = []
 
     def __del__(self):
         if getattr(self, "_h", None) and capi is not None:
             capi.load().l3k_mf_destroy(self._h)
             self._h = None
+
+    def attach_boundary(self, term):
+        """Registers a BoundaryTerm: apply / apply_elems / diag_rhs include it from now on."""
+        check(capi.load().l3k_mf_attach_boundary(self._h, term._h))
+        self._boundary_terms.append(term)  # keeps the term alive as long as the system
 
     # post::FieldAccess: SoA (n_fields, n_local_nodes) device tensor, kept alive here
     def set_fields(self, fields):

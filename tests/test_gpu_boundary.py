@@ -1,0 +1,169 @@
+"""GPU parity of the boundary-kernel terms and the post-processing integrals through the C ABI:
+against the oracle on the same inputs, against the reference's side-area known answers, and end to end on 3-D twins of
+the reference's K6 (exact linear solution with an adiabatic boundary kernel) and K7 (benchmarks/Diffusion3D.hpp)."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from l3ster_amd import system
+    return system
+
+
+@pytest.fixture(scope="module")
+def ctx(S):
+    torch.cuda.set_device(0)
+    return S.Context(0, torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+
+
+HEXM = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1.5], [0, 1, 1.5], [1, 1, 2]], float)
+
+
+def test_side_areas_and_volume(S, ctx):
+    # tests/MappingTests.cpp:555-610: quadrature order 10 (6 points) on the order-1 hex
+    part = helpers.SingleElementMesh(1, HEXM)
+    mesh = S.DeviceMesh(ctx, part, 1)
+    opts = (5, 0, 0)
+    assert S.n_qps1d(1, 5, 0) == 6
+    for side, area in enumerate([1.0, np.sqrt(1.5), 1.25, 1.75, 1.25, 1.75]):
+        got = S.integrate(mesh, S.RESIDUAL_UNIT3D, asm_opts=opts, face_elem=[0], face_side=[side])
+        assert got[0] == pytest.approx(area, abs=1e-13)
+    vol = S.integrate(mesh, S.RESIDUAL_UNIT3D, asm_opts=opts)
+    want = O.integrate_local(-1, O.RESIDUAL_UNIT3D, 1, 6, HEXM, None)
+    assert vol[0] == pytest.approx(want[0], rel=1e-13)
+
+
+def _setup(S, ctx, ne, p, perturb=0.15, dir_sides=(0, 5)):
+    part = S.CubePartition(ne, p, perturb=perturb)
+    U = 4
+    mask = part.dirichlet_mask(U, sides=dir_sides)
+    mesh = S.DeviceMesh(ctx, part, U, mask)
+    return part, mesh, mask, U
+
+
+@pytest.mark.parametrize("p,opts,R", [(2, (1, 0, 0), 1), (2, (1, 0, 0), 2), (4, (1, 0, 0), 1), (3, (2, 0, 0), 1)])
+def test_boundary_term_vs_oracle(S, ctx, p, opts, R):
+    part, mesh, mask, U = _setup(S, ctx, 3, p)
+    nq = S.n_qps1d(p, *opts[:2])
+    kp = [2.0, 0.7]
+    fe, fs = part.boundary_sides([1, 3, 4, 2])
+    term = S.BoundaryTerm(mesh, S.KERNEL_ROBIN3D, fe, fs, kernel_params=kp, asm_opts=opts, n_rhs=R)
+    om = helpers.oracle_mesh(part, nq, U, [0, 1, 2, 3], dirichlet=mask)
+    rng = np.random.default_rng(p)
+    x = rng.standard_normal((R, part.n_local_nodes * U))
+    y0 = rng.standard_normal((R, part.n_local_nodes * U))
+    Y = dev(y0)
+    term.apply(dev(x), Y, alpha=1.5)
+    want = np.asfortranarray(y0.T.copy())
+    O.bnd_apply(om, O.KERNEL_ROBIN3D, fe, fs, np.asfortranarray(x.T), want, alpha=1.5, kparams=kp)
+    assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-12
+    # diag / rhs with Dirichlet lifting
+    g = np.where(mask[None, :] != 0, rng.standard_normal((R, mask.size)), 0.0)
+    diag = torch.zeros(mask.size, dtype=torch.float64, device="cuda")
+    rhs = torch.zeros((R, mask.size), dtype=torch.float64, device="cuda")
+    term.diag_rhs(diag, rhs, dirichlet_vals=dev(g))
+    wd = np.zeros(mask.size)
+    wr = np.zeros((mask.size, R), order="F")
+    O.bnd_diag_rhs(om, O.KERNEL_ROBIN3D, fe, fs, wd, wr, dirichlet_vals=np.asfortranarray(g.T), kparams=kp)
+    assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-12
+    assert helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-11
+
+
+def test_attached_boundary_in_apply(S, ctx):
+    p = 2
+    part, mesh, mask, U = _setup(S, ctx, 4, p)
+    nq = S.n_qps1d(p)
+    fe, fs = part.boundary_sides([1, 2, 3, 4])
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    term = S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, fe, fs)
+    mf.attach_boundary(term)
+    om = helpers.oracle_mesh(part, nq, U, [0, 1, 2, 3], dirichlet=mask)
+    x = part.synthetic_vector(U, seed=3)
+    y0 = part.synthetic_vector(U, seed=4)
+    Y = dev(y0)
+    mf.apply(dev(x), Y, alpha=0.5, beta=-2.0)
+    want = O.mf_apply(om, O.KERNEL_DIFFUSION3D, x.T, y=np.asfortranarray(y0.T.copy()), alpha=0.5, beta=-2.0, kparams=[1.0, 1.0])
+    # the boundary rows are added before the Dirichlet rows in the device schedule; both commute
+    O.bnd_apply(om, O.KERNEL_ADIABATIC3D, fe, fs, np.asfortranarray(x.T), want, alpha=0.5)
+    assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-12
+    diag, rhs = mf.diag_rhs(None)
+    wd, wr = O.mf_diag_rhs(om, O.KERNEL_DIFFUSION3D, kparams=[1.0, 1.0], finalize=False)
+    O.bnd_diag_rhs(om, O.KERNEL_ADIABATIC3D, fe, fs, wd, wr)
+    wd[mask != 0] = 1.0
+    wr[mask != 0] = 0.0
+    assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-12
+    assert helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-11
+
+
+def test_k6_twin_linear_solution_with_adiabatic_walls(S, ctx):
+    """3-D twin of tests/Diffusion2D.hpp on the device: first-order diffusion system without source, Dirichlet T = x on
+    the x- and x+ sides, adiabatic boundary kernel on the other four, distorted mesh.  T = x, q = (1,0,0) lies in the
+    discrete space, so the least-squares solution reproduces it: L2 errors < 1e-8 on the domain and the boundary."""
+    from l3ster_amd import solve
+    p, ne, U = 2, 4, 4
+    part = S.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U, sides=(4, 5))
+    mesh = S.DeviceMesh(ctx, part, U, mask)
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 0.0])  # k = 1, s = 0
+    fe, fs = part.boundary_sides([0, 1, 2, 3])
+    mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, fe, fs))
+    coords = part.node_coords()
+    g = np.zeros((part.n_local_nodes, U))
+    g[:, 0] = coords[:, 0]
+    g = np.where(mask.reshape(-1, U) != 0, g, 0.0).reshape(1, -1)
+    diag, rhs = mf.diag_rhs(dev(g))
+    x = torch.zeros_like(diag)
+    res = solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x, solve.jacobi_inverse(diag), tol=1e-12,
+                   residual_scaling="rhs", max_iters=5000)
+    assert res.converged
+    sol = x.view(-1, U)
+    assert (sol[:, 0] - dev(coords[:, 0])).abs().max().item() < 1e-9
+    fields = sol.T.contiguous()  # SolutionManager layout: SoA [field][node]
+    err = S.norm_l2(mesh, S.RESIDUAL_LINEAR3D_ERROR, fields)
+    all_fe, all_fs = part.boundary_sides(range(6))
+    berr = S.norm_l2(mesh, S.RESIDUAL_LINEAR3D_ERROR, fields, face_elem=all_fe, face_side=all_fs)
+    assert np.linalg.norm(err) < 1e-8 and np.linalg.norm(berr) < 1e-8  # tests/Diffusion2D.hpp:117-119
+    # oracle parity of the two norms on the same solution (values are ~1e-10: compare the squared integrals absolutely)
+    om = O.MeshView(3, p, S.n_qps1d(p), part.elem_nodes, part.elem_verts, part.n_local_nodes, U, [0, 1, 2, 3],
+                    fields=fields.cpu().numpy())
+    nq2 = S.n_qps1d(p, 2, 0)
+    assert np.allclose(err ** 2, O.mf_integrate(om, O.RESIDUAL_LINEAR3D_ERROR, nq2, square=True), atol=1e-18, rtol=1e-6)
+    area = S.integrate(mesh, S.RESIDUAL_UNIT3D, asm_opts=(2, 0, 0), face_elem=all_fe, face_side=all_fs)
+    assert area[0] == pytest.approx(O.mf_integrate(om, O.RESIDUAL_UNIT3D, nq2, face_elem=all_fe, face_side=all_fs)[0], rel=1e-13)
+
+
+def test_k7_diffusion3d_benchmark_error_norms(S, ctx):
+    """benchmarks/Diffusion3D.hpp:80-135 end to end on the device: 6^3 hexes of order 6 on [0,1]^3, T = 0 on the six
+    sides, k = s = 1, Jacobi-PCG, then the four L2 residual components (the reference prints them without a threshold).
+    Parity: the same four numbers from the oracle on the device solution; sanity: they are small."""
+    from l3ster_amd import solve
+    p, ne, U = 6, 6, 4
+    part = S.CubePartition(ne, p)
+    mask = part.dirichlet_mask(U)
+    mesh = S.DeviceMesh(ctx, part, U, mask)
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    diag, rhs = mf.diag_rhs(None)
+    x = torch.zeros_like(diag)
+    res = solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x, solve.jacobi_inverse(diag), tol=1e-10,
+                   residual_scaling="rhs", max_iters=20000)
+    assert res.converged
+    fields = x.view(-1, U).T.contiguous()
+    err = S.norm_l2(mesh, S.RESIDUAL_DIFFUSION3D_ERROR, fields, kernel_params=[1.0, 1.0])
+    om = O.MeshView(3, p, S.n_qps1d(p), part.elem_nodes, part.elem_verts, part.n_local_nodes, U, [0, 1, 2, 3],
+                    fields=fields.cpu().numpy())
+    want = np.sqrt(O.mf_integrate(om, O.RESIDUAL_DIFFUSION3D_ERROR, S.n_qps1d(p, 2, 0), square=True, kparams=[1.0, 1.0]))
+    assert np.allclose(err, want, rtol=1e-9, atol=0)
+    assert np.all(err < 5e-2) and err[1:].max() < 1e-3
+    # T is positive inside, zero on the boundary; the maximum of the Poisson solution on the unit cube is ~0.0562
+    assert x.view(-1, U)[:, 0].max().item() == pytest.approx(0.0562, abs=2e-3)
