@@ -6,6 +6,9 @@
 //       .apply(X, Y, alpha, beta)   ~ Operator::apply                                      :34-41
 //       .diagAndRhs(...)            ~ endAssembly() -> computeDiagAndRhs                   :877-941
 //       .assembleLocal(...)         ~ assembleLocalSystem                                  algsys/AssembleLocalSystem.hpp:234-256
+//       .assembleProblem(bnd)       ~ assembleProblem(boundary kernel, boundary_ids)      algsys/MatrixFreeSystem.hpp:58-68
+//   l3k::BoundaryTerm            ~ a BoundaryEquationKernel on a set of boundary views   algsys/EvaluateLocalOperator.hpp:238-330
+//   l3k::computeIntegral / computeNormL2 ~ post/Integral.hpp:113-128, post/NormL2.hpp:31-62 (one rank)
 // Errors: the reference throws std::runtime_error from util::throwingAssert (util/Assertion.hpp:88-95); so does this
 // wrapper, with the text of l3k_last_error().  RAII handles, no torch, no other dependency than l3k.h + the HIP runtime
 // of the caller for device memory.
@@ -15,6 +18,7 @@
 #include "l3k.h"
 
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <span>
 #include <stdexcept>
@@ -64,6 +68,26 @@ public:
     ~CubeMesh() { l3k_hostmesh_destroy(m_mesh); }
     const l3k_hostmesh_view& view() const { return m_view; }
     int64_t                  nLocalNodes() const { return m_view.n_owned_nodes + m_view.n_ghost_nodes; }
+    // the boundary views of makeCubeMesh (mesh/primitives/CubeMesh.hpp:66-138): (element, side) pairs of this rank's
+    // element sides on the cube sides selected by bit s of `sides`
+    struct Sides
+    {
+        std::vector< int64_t > elems;
+        std::vector< uint8_t > sides;
+    };
+    Sides boundarySides(unsigned sides = 0x3f) const
+    {
+        Sides out;
+        for (int s = 0; s < 6; ++s)
+            if (sides & (1u << s))
+                for (int64_t e = 0; e < m_view.n_elems; ++e)
+                    if (m_view.elem_boundary[e] & (1u << s))
+                    {
+                        out.elems.push_back(e);
+                        out.sides.push_back(static_cast< uint8_t >(s));
+                    }
+        return out;
+    }
     // BCDefinition::defineDirichlet(boundary_ids, {unknowns}) as a byte mask over local dofs; sides as in
     // mesh/ElementTraits.hpp:84-95 (bit s of `sides`)
     std::vector< uint8_t > dirichletMask(int dofs_per_node, std::span< const int > unknowns, unsigned sides = 0x3f) const
@@ -107,6 +131,65 @@ private:
     int       m_dpn{};
 };
 
+// A boundary equation kernel on a list of element sides (the reference's assembleProblem(kernel, boundary_ids))
+class BoundaryTerm
+{
+public:
+    template < typename KernelParamBlock >
+    BoundaryTerm(const DeviceMesh& mesh, int kernel_id, const KernelParamBlock& params, const CubeMesh::Sides& sides,
+                 AssemblyOptions opts = {}, std::span< const int > field_inds = {}, int n_rhs = 1)
+    {
+        const l3k_asmopts o{opts.value_order, opts.derivative_order, opts.eval_strategy};
+        check(l3k_bnd_create(mesh.ctx(), mesh.get(), kernel_id, &params, sizeof params, &o,
+                             field_inds.empty() ? nullptr : field_inds.data(), n_rhs, int64_t(sides.elems.size()),
+                             sides.elems.data(), sides.sides.data(), &m_bnd));
+    }
+    BoundaryTerm(const DeviceMesh& mesh, int kernel_id, const CubeMesh::Sides& sides, AssemblyOptions opts = {}, int n_rhs = 1)
+    {
+        const l3k_asmopts o{opts.value_order, opts.derivative_order, opts.eval_strategy};
+        check(l3k_bnd_create(mesh.ctx(), mesh.get(), kernel_id, nullptr, 0, &o, nullptr, n_rhs,
+                             int64_t(sides.elems.size()), sides.elems.data(), sides.sides.data(), &m_bnd));
+    }
+    BoundaryTerm(const BoundaryTerm&)            = delete;
+    BoundaryTerm& operator=(const BoundaryTerm&) = delete;
+    ~BoundaryTerm() { l3k_bnd_destroy(m_bnd); }
+    void     setFields(const double* d_soa, size_t ld) { check(l3k_bnd_set_fields(m_bnd, d_soa, ld)); }
+    l3k_bnd* get() const { return m_bnd; }
+
+private:
+    l3k_bnd* m_bnd{};
+};
+
+// computeIntegral (post/Integral.hpp:113-128) for one rank: integral of a residual kernel over the mesh (sides == nullptr)
+// or over element sides; fields = SoA device array [n_fields][ld]
+template < typename KernelParamBlock >
+std::vector< double > computeIntegral(const DeviceMesh& mesh, int residual_id, const KernelParamBlock* params,
+                                      const double* d_fields, size_t ldf, AssemblyOptions opts = {},
+                                      const CubeMesh::Sides* sides = nullptr, bool square = false, double time = 0.)
+{
+    l3k_kparams kp{};
+    check(l3k_residual_info(residual_id, &kp, nullptr, nullptr));
+    std::vector< double > out(static_cast< size_t >(kp.n_equations));
+    const l3k_asmopts     o{opts.value_order, opts.derivative_order, opts.eval_strategy};
+    check(l3k_integrate(mesh.ctx(), mesh.get(), residual_id, params, params ? sizeof(KernelParamBlock) : 0, &o, d_fields,
+                        ldf, time, square ? 1 : 0, sides ? int64_t(sides->elems.size()) : -1,
+                        sides ? sides->elems.data() : nullptr, sides ? sides->sides.data() : nullptr, out.data()));
+    return out;
+}
+// computeNormL2 (post/NormL2.hpp:31-62): squared residual, doubled quadrature orders, square root
+template < typename KernelParamBlock >
+std::vector< double > computeNormL2(const DeviceMesh& mesh, int residual_id, const KernelParamBlock* params,
+                                    const double* d_fields, size_t ldf, AssemblyOptions opts = {},
+                                    const CubeMesh::Sides* sides = nullptr, double time = 0.)
+{
+    opts.value_order *= 2;
+    opts.derivative_order *= 2;
+    auto out = computeIntegral(mesh, residual_id, params, d_fields, ldf, opts, sides, true, time);
+    for (auto& v : out)
+        v = std::sqrt(v);
+    return out;
+}
+
 // algsys::MatrixFreeSystem for one rank without ghosts.  Kernel = registered functor id + POD parameter block
 // (l3ster_amd/csrc/user_kernels.hpp); vectors are DEVICE pointers, column-major with leading dimension.
 class MatrixFreeSystem
@@ -131,6 +214,9 @@ public:
 
     void setFields(const double* d_soa, size_t ld) { check(l3k_mf_set_fields(m_mf, d_soa, ld)); } // post::FieldAccess
     void setTime(double t) { check(l3k_mf_set_time(m_mf, t)); }
+    // assembleProblem(boundary kernel, boundary ids): the term takes part in apply / diagAndRhs from now on and must
+    // outlive this system
+    void assembleProblem(const BoundaryTerm& term) { check(l3k_mf_attach_boundary(m_mf, term.get())); }
     // Y <- alpha*A*X + beta*Y (Operator::apply; the operator is symmetric, `mode` is ignored by the reference too)
     void apply(const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols = 1, double alpha = 1., double beta = 0.) const
     {

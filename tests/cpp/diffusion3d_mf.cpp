@@ -1,7 +1,9 @@
 // diffusion3d_mf.cpp -- the C++ host shim (include/l3k/operator.hpp) used the way the reference's own tests use its
 // API: (1) single distorted element: matrix-free apply == K_e * x with K_e from LocalAssembly (the property
 // tests/LocalOperatorTests.cpp:3-95 checks, < 1e-8); (2) a Dirichlet-constrained mesh operator is symmetric,
-// <A x, z> = <x, A z> (Operator::apply ignores `mode`, algsys/MatrixFreeSystem.hpp:34-41).
+// <A x, z> = <x, A z> (Operator::apply ignores `mode`, algsys/MatrixFreeSystem.hpp:34-41); (3) a boundary term attached
+// with assembleProblem keeps the operator symmetric, and the surface of the unit cube integrates to 6, its volume to 1
+// (the side-area check of tests/MappingTests.cpp:555-610 on a mesh).
 // Build: hipcc -std=c++20 -Iinclude tests/cpp/diffusion3d_mf.cpp -Ll3ster_amd/lib -ll3k -o /tmp/diffusion3d_mf
 #include "l3k/operator.hpp"
 
@@ -105,6 +107,48 @@ int main()
         }
         std::printf("symmetry: <Ax,z> = %.15e, <x,Az> = %.15e\n", s1, s2);
         failures += !(std::fabs(s1 - s2) < 1e-11 * std::fabs(s1));
+    }
+    { // (3) boundary term + integrals
+        constexpr int         p = 2, U = 4;
+        l3k::CubeMesh         mesh{{3, 3, 3}, p, {1, 1, 1}, 0, 0.};
+        const int             unknowns[] = {0};
+        const auto            mask = mesh.dirichletMask(U, unknowns, 0x30); // x- and x+ sides
+        l3k::DeviceMesh       dmesh{ctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        struct RobinParams
+        {
+            double h, t_inf;
+        } robin{2., 0.5};
+        const auto        walls = mesh.boundarySides(0x0f);
+        l3k::BoundaryTerm term{dmesh, L3K_KERNEL_ROBIN3D, robin, walls};
+        sys.assembleProblem(term);
+        const size_t          n = static_cast< size_t >(dmesh.nOwnedDofs());
+        std::vector< double > x(n), z(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            x[i] = dist(prng);
+            z[i] = dist(prng);
+        }
+        DevVec dx{n}, dz{n}, dax{n}, daz{n};
+        dx.up(x);
+        dz.up(z);
+        sys.apply(dx.p, n, dax.p, n);
+        sys.apply(dz.p, n, daz.p, n);
+        ctx.synchronize();
+        const auto ax = dax.down(), az = daz.down();
+        double     s1 = 0., s2 = 0.;
+        for (size_t i = 0; i < n; ++i)
+        {
+            s1 += ax[i] * z[i];
+            s2 += x[i] * az[i];
+        }
+        std::printf("symmetry with boundary term: <Ax,z> = %.15e, <x,Az> = %.15e\n", s1, s2);
+        failures += !(std::fabs(s1 - s2) < 1e-11 * std::fabs(s1));
+        const auto all  = mesh.boundarySides();
+        const auto area = l3k::computeIntegral< RobinParams >(dmesh, L3K_RESIDUAL_UNIT3D, nullptr, nullptr, 0, {}, &all);
+        const auto vol  = l3k::computeIntegral< RobinParams >(dmesh, L3K_RESIDUAL_UNIT3D, nullptr, nullptr, 0);
+        std::printf("surface = %.15f, volume = %.15f\n", area[0], vol[0]);
+        failures += !(std::fabs(area[0] - 6.) < 1e-12 && std::fabs(vol[0] - 1.) < 1e-13);
     }
     try
     { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)

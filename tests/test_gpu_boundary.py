@@ -167,3 +167,58 @@ def test_k7_diffusion3d_benchmark_error_norms(S, ctx):
     assert np.all(err < 5e-2) and err[1:].max() < 1e-3
     # T is positive inside, zero on the boundary; the maximum of the Poisson solution on the unit cube is ~0.0562
     assert x.view(-1, U)[:, 0].max().item() == pytest.approx(0.0562, abs=2e-3)
+
+
+@pytest.mark.parametrize("ne,parts", [((4, 2, 2), (2, 1, 1)), ((4, 4, 2), (2, 2, 1))])
+def test_boundary_term_in_multi_rank_schedule(S, ctx, ne, parts):
+    """A boundary term attached on every rank takes part in the split-phase schedule (sides of interior elements with the
+    interior launch, sides of border elements after the import): the assembled result equals the oracle on the whole
+    mesh.  Ranks are threads sharing the GPU (ThreadTransport of test_gpu_apply.py)."""
+    import queue
+    import threading
+    from l3ster_amd.distributed import DistributedOperator, HaloPlan
+    from test_gpu_apply import ThreadTransport
+    p, U, kp = 2, 4, [2.0, 0.7]
+    sides = [1, 3, 4, 5]
+    world = int(np.prod(parts))
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    out, errors = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            part = S.CubePartition(ne, p, parts, rank, perturb=0.1)
+            mask = part.dirichlet_mask(U, sides=(0, 2))
+            c = S.Context(0, torch.cuda.current_stream().cuda_stream)
+            mesh = S.DeviceMesh(c, part, U, mask)
+            mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [0.7, 1.0])
+            mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ROBIN3D, *part.boundary_sides(sides), kernel_params=kp))
+            n_owned = part.n_owned_nodes * U
+            X = dev(part.synthetic_vector(U)[:, :n_owned])
+            Y = dev(part.synthetic_vector(U, seed=7)[:, :n_owned])
+            op = DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes))
+            op.apply(X, Y, 1.25, -0.5)
+            torch.cuda.synchronize()
+            out[rank] = (Y.cpu().numpy(), part.node_grid_id[:part.n_owned_nodes].copy())
+        except Exception as exc:  # pragma: no cover
+            errors.append((rank, exc))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    whole = S.CubePartition(ne, p, perturb=0.1)
+    mask = whole.dirichlet_mask(U, sides=(0, 2))
+    om = helpers.oracle_mesh(whole, p + 1, U, np.arange(U), mask)
+    x, y0 = whole.synthetic_vector(U), whole.synthetic_vector(U, seed=7)
+    y_ref = O.mf_apply(om, O.KERNEL_DIFFUSION3D, x.T, np.asfortranarray(y0.T.copy()), alpha=1.25, beta=-0.5,
+                       kparams=[0.7, 1.0])
+    O.bnd_apply(om, O.KERNEL_ROBIN3D, *whole.boundary_sides(sides), np.asfortranarray(x.T), y_ref, alpha=1.25, kparams=kp)
+    row_of = {int(g): i for i, g in enumerate(whole.node_grid_id)}
+    for r in range(world):
+        y, gid = out[r]
+        rows = np.array([row_of[int(g)] for g in gid])
+        ref = y_ref.reshape(whole.n_local_nodes, U)[rows]
+        assert np.linalg.norm(y.reshape(len(rows), U) - ref) < 1e-11 * np.linalg.norm(ref)
