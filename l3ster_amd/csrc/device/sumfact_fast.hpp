@@ -48,16 +48,30 @@ __device__ __forceinline__ void sweepEO(const double (&in)[NIN], double (&out)[N
 #pragma unroll
     for (int q = 0; q < HO; ++q)
     {
-        double A = 0., B = 0.;
+        double A = 0.;
 #pragma unroll
         for (int r = 0; r < RI; ++r)
             A += e[r] * We[r * RO + q];
+        if constexpr (ACC)
+        {
+            double B = 0.;
 #pragma unroll
-        for (int r = 0; r < HI; ++r)
-            B += o[r] * Wo[r * RO + q];
-        const double lo = A + B, hi = ANTI ? B - A : A - B;
-        out[q]            = ACC ? out[q] + lo : lo;
-        out[NOUT - 1 - q] = ACC ? out[NOUT - 1 - q] + hi : hi;
+            for (int r = 0; r < HI; ++r)
+                B += o[r] * Wo[r * RO + q];
+            out[q] += A + B;
+            out[NOUT - 1 - q] += ANTI ? B - A : A - B;
+        }
+        else
+        {
+            // lo = A + B with the odd part accumulated onto A (no separate B, no add); hi = A - B = 2A - lo: one
+            // instruction less per output pair than forming A, B, A + B, A - B
+            double lo = A;
+#pragma unroll
+            for (int r = 0; r < HI; ++r)
+                lo += o[r] * Wo[r * RO + q];
+            out[q]            = lo;
+            out[NOUT - 1 - q] = ANTI ? lo - 2. * A : 2. * A - lo;
+        }
     }
     if constexpr (NOUT % 2)
     {
@@ -246,7 +260,13 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    u0[k][u] = (dm_nxt[k] >> u) & 1u ? 0. : xn[k][u];
+                    u0[k][u] = xn[k][u];
+                if (flag_cur != 0) // wave-uniform: only elements touching a Dirichlet dof pay for the masking
+                {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        u0[k][u] = (dm_nxt[k] >> u) & 1u ? 0. : u0[k][u];
+                }
 #pragma unroll
                 for (int f = 0; f < F; ++f)
                     u0[k][U + f] = fn[k][f];
@@ -628,6 +648,12 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                     }
                     else
                     {
+                        if (a.dbg & 96) // ablation: 32 = plain 16-byte store instead of the atomics, 64 = no memory operation
+                        {
+                            if ((a.dbg & 32) || val.x == 1.2345e300)
+                                *reinterpret_cast< double2* >(dst) = val;
+                            continue;
+                        }
                         if (!d0)
                         {
                             if (a.dbg & 16)
