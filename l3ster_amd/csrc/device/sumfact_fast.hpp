@@ -145,7 +145,7 @@ struct FastCfg
 #endif
 template < typename K, int P, int NQ >
 __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
-                                                        const FastTables< P + 1, NQ > tab)
+                                                        int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
     using Cfg = FastCfg< K, P, NQ >;
     constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
@@ -182,16 +182,26 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
     auto ldg = [&](const double2* buf, int g, int idx) { return buf[g * OS + idx]; };
     auto stg = [&](double2* buf, int g, int idx, double x0, double x1) { buf[g * OS + idx] = make_double2(x0, x1); };
 
+    // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (workgroups b and b + 8 share an XCD and its L2).
+    // The c-th group of workgroups takes the c-th contiguous eighth of the (brick-ordered) element batches and sweeps it
+    // together, so elements that share node rows of x are resident in the same L2 at the same time.  32-bit loop state:
+    // the kernel is at its register limit and 64-bit counters were spilled.
+    const int nb     = static_cast< int >(n_batches);
+    const int by_xcd = xcd_chunk > 0;
+    const int stride = by_xcd ? int(gridDim.x) >> 3 : int(gridDim.x);
+    const int first  = by_xcd ? int(blockIdx.x & 7) * xcd_chunk : 0;
+    const int last   = by_xcd ? (first + xcd_chunk < nb ? first + xcd_chunk : nb) : nb;
+    int       batch  = first + (by_xcd ? int(blockIdx.x >> 3) : int(blockIdx.x));
     // ---- software pipeline state: node ids two batches ahead, x values one batch ahead
     uint32_t      ids_cur[N1], ids_nxt[N1];
     double        xn[N1][U];
     double        fn[N1][F > 0 ? F : 1];
     uint32_t      dm_nxt[N1];
     const int64_t n_owned_nodes = a.n_owned_dofs / U;
-    auto          elemOf = [&](int64_t batch) { return a.elem_begin + batch * EW + team; };
-    auto valid   = [&](int64_t batch) { return batch < n_batches && on_nn && (batch * EW + team) < a.elem_count; };
+    auto          elemOf = [&](int b) { return a.elem_begin + int64_t(b) * EW + team; };
+    auto          valid  = [&](int b) { return b < last && on_nn && (int64_t(b) * EW + team) < a.elem_count; };
     const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
-    auto       loadIds    = [&](int64_t batch, uint32_t (&ids)[N1], uint32_t& flag) {
+    auto       loadIds    = [&](int batch, uint32_t (&ids)[N1], uint32_t& flag) {
         flag = 0;
         if (valid(batch))
         {
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                 flag = a.elem_flags[elemOf(batch)];
         }
     };
-    auto loadX = [&](int64_t batch, const uint32_t (&ids)[N1], bool flagged) {
+    auto loadX = [&](int batch, const uint32_t (&ids)[N1], bool flagged) {
         if (!valid(batch))
             return;
         // node-interleaved dofs with the kernel's unknowns = all dofs of a node (the launcher sends every other layout
@@ -240,13 +250,12 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
     const double eta_l = qp[qa < NQ ? qa : 0], zeta_l = qp[qb < NQ ? qb : 0];
     const double wyz_l = qw[qa < NQ ? qa : 0] * qw[qb < NQ ? qb : 0];
 
-    int64_t  batch = blockIdx.x;
     uint32_t flag_cur, flag_nxt = 0;
     loadIds(batch, ids_cur, flag_cur);
 
-    for (; batch < n_batches; batch += gridDim.x)
+    for (; batch < last; batch += stride)
     {
-        const bool act = (batch * EW + team) < a.elem_count; // this team has an element in this batch
+        const bool act = (int64_t(batch) * EW + team) < a.elem_count; // this team has an element in this batch
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                 idsL[i1 + N1 * (j1 + N1 * k)] = ids_cur[k];
         }
         stageFence();
-        loadIds(batch + gridDim.x, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
+        loadIds(batch + stride, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
         // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
         if (act)
@@ -759,7 +768,14 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     __builtin_memcpy(tab.eoCt, th + TL.offEoCt(), sizeof tab.eoCt);
     __builtin_memcpy(tab.qw, th + TL.offW(), sizeof tab.qw);
     __builtin_memcpy(tab.qx, th + TL.offX(), sizeof tab.qx);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, tab);
+    // contiguous eighths per XCD only when every XCD group gets the same number of persistent workgroups
+    static const bool xcd_env   = std::getenv("L3K_FAST_NO_XCD") == nullptr;
+    // measured (profiles/r01_kbench_xcd_mapping.log): order 6 gains 1 % and re-fetches less, order 4 loses 11 % (the
+    // elements in flight on one XCD are neighbours: their atomics meet on the same lines)
+    const int         xcd_chunk = (P >= 6 && xcd_env && grid % 8 == 0 && n_batches >= int64_t(grid) && n_batches < (int64_t(1) << 30))
+                                      ? int((n_batches + 7) / 8)
+                                      : 0;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
     {
