@@ -198,6 +198,46 @@ int l3k_integrate(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kpa
                   const l3k_asmopts* opts, const double* d_fields, size_t ldf, double time, int square, int64_t n_faces,
                   const int64_t* face_elem, const uint8_t* face_side, double* h_out);
 
+/* ---- Jacobi-preconditioned conjugate gradients ------------------------------------------------------------------------
+ * The reference hands the iteration to Trilinos Belos ("Block CG", solve/BelosSolvers.hpp:116-122) with its native Jacobi
+ * preconditioner (solve/NativePreconditioners.hpp:36-96); Belos is not part of the reference tree, the arithmetic here
+ * is the textbook Hestenes-Stiefel PCG for one column, pinned end to end.  Everything stays on the
+ * context's stream; dot products are two-stage reductions in a fixed order.
+ *   l3k_jacobi_inverse : minv = sign(d) * damping / max(|d|, threshold)          (NativeJacobiImpl::init :75-96)
+ *   l3k_pcg_solve      : single rank (no ghost nodes); x holds the initial guess and the result; d_minv may be NULL;
+ *                        residual_scaling 0 none / 1 initial residual / 2 norm of b (IterSolverOpts,
+ *                        solve/SolverInterface.hpp:26-37); check_every = iterations between convergence checks (each is
+ *                        one 32-byte device-to-host copy)
+ *   l3k_cg_*           : the fused vector kernels of one iteration for partitioned vectors: the caller all-reduces the
+ *                        device scalar block s[8] (0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>) between them:
+ *                          init:      r <- b - r (r = A x0 on entry), p <- minv r, s[2] = s[0] = <r,p>, s[3] = <r,r>
+ *                          dot_pAp:   s[1] = <p, Ap>
+ *                          update_xr: alpha = s[0]/s[1]; x += alpha p; r -= alpha Ap; s[2] = <r, minv r>; s[3] = <r,r>
+ *                          update_p:  beta = s[2]/s[0]; p = minv r + beta p; then s[0] <- s[2]
+ *                        (init and update_xr write LOCAL sums into s[2], s[3]; all-reduce them before the next call;
+ *                        after init also copy s[2] to s[0] once the reduced value is in place) */
+typedef struct
+{
+    double tol;
+    int    max_iters;
+    int    residual_scaling;
+    int    check_every;
+} l3k_cg_opts;
+typedef struct
+{
+    double achieved_tol;
+    int    iterations;
+    int    converged;
+} l3k_cg_result;
+int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv);
+int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_minv, const l3k_cg_opts* opts,
+                  l3k_cg_result* result);
+int l3k_cg_init(l3k_ctx* ctx, double* d_r, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s);
+int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t n, double* d_s);
+int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
+                     int64_t n, double* d_s);
+int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s);
+
 /* ---- LocalAssembly --------------------------------------------------------------------------------------------------
  * assembleLocalSystem for a batch of elements, algsys/AssembleLocalSystem.hpp:234-256: K_e row-major [Nd][Nd],
  * F_e column-major [Nd][n_rhs] per element, elements [first, first+count).  d_K may be NULL (then only the checksum

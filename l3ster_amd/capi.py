@@ -26,6 +26,14 @@ class AsmOpts(C.Structure):
     _fields_ = [("value_order", C.c_int), ("derivative_order", C.c_int), ("eval_strategy", C.c_int)]
 
 
+class CgOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iters", C.c_int), ("residual_scaling", C.c_int), ("check_every", C.c_int)]
+
+
+class CgResult(C.Structure):
+    _fields_ = [("achieved_tol", C.c_double), ("iterations", C.c_int), ("converged", C.c_int)]
+
+
 class MeshDesc(C.Structure):
     _fields_ = [("dim", C.c_int), ("order", C.c_int), ("n_elems", C.c_int64), ("n_interior_elems", C.c_int64),
                 ("elem_nodes", c_uint32_p), ("elem_verts", c_double_p), ("n_owned_nodes", C.c_int64),
@@ -86,6 +94,12 @@ SIGNATURES = {
     "l3k_residual_info": (C.c_int, [C.c_int, C.POINTER(KParams), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
     "l3k_integrate": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), _vp, C.c_size_t, C.c_double,
                                 C.c_int, C.c_int64, c_int64_p, c_uint8_p, c_double_p]),
+    "l3k_jacobi_inverse": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, C.c_double, _vp]),
+    "l3k_pcg_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(CgOpts), C.POINTER(CgResult)]),
+    "l3k_cg_init": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_cg_dot_pap": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_cg_update_xr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_cg_update_p": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "l3k_cube_partition_create": (C.c_int, [c_int_p, C.c_int, c_int_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     "l3k_hostmesh_destroy": (C.c_int, [_vp]),
     "l3k_hostmesh_view_get": (C.c_int, [_vp, C.POINTER(HostMeshView)]),

@@ -64,3 +64,74 @@ def cg(apply, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="non
     if throw_on_fail and not converged:
         raise RuntimeError("Solver failed to converge")  # solve/BelosSolvers.hpp:103
     return IterSolveResult(res, it, converged)
+
+
+def jacobi_inverse_native(ctx, diag, damping=1.0, threshold=0.0):
+    """NativeJacobiImpl::init through the C ABI (l3k_jacobi_inverse)."""
+    import ctypes as C
+    from . import capi
+    out = torch.empty_like(diag)
+    capi.check(capi.load().l3k_jacobi_inverse(ctx._h, C.c_void_p(diag.data_ptr()), diag.numel(), float(damping),
+                                              float(threshold), C.c_void_p(out.data_ptr())))
+    return out
+
+
+_SCALING = {"none": 0, "initial": 1, "rhs": 2}
+
+
+def pcg(system, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="none", check_every=1, throw_on_fail=True):
+    """Jacobi-PCG entirely behind the C ABI (l3k_pcg_solve): apply, fused vector updates and reductions run on the
+    context's stream, the host only reads 32 bytes per convergence check.  Single rank; `system` is a
+    l3ster_amd.system.MatrixFreeSystem, b / x / minv 1-D device tensors over its owned dofs."""
+    import ctypes as C
+    from . import capi
+    opts = capi.CgOpts(float(tol), int(max_iters), _SCALING[residual_scaling], int(check_every))
+    res = capi.CgResult()
+    capi.check(capi.load().l3k_pcg_solve(system._h, C.c_void_p(b.data_ptr()), C.c_void_p(x.data_ptr()),
+                                         C.c_void_p(0 if minv is None else minv.data_ptr()), C.byref(opts), C.byref(res)))
+    if throw_on_fail and not res.converged:
+        raise RuntimeError("Solver failed to converge")  # solve/BelosSolvers.hpp:103
+    return IterSolveResult(res.achieved_tol, res.iterations, bool(res.converged))
+
+
+def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="none", group=None,
+                    throw_on_fail=True):
+    """The same iteration for a partitioned system: `op.apply(X, Y)` is a DistributedOperator over this rank's owned
+    rows; the fused l3k_cg_* kernels keep the scalars in a device block that is all-reduced between them (two small
+    all-reduces per iteration, as Belos does)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.load()
+    n = b.numel()
+    vp = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    s = torch.zeros(8, dtype=torch.float64, device=b.device)
+    r, p, ap = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def reduce(view):
+        if multi:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+
+    op.apply(x[None, :], r[None, :])
+    capi.check(lib.l3k_cg_init(ctx._h, vp(r), vp(b), vp(p), vp(minv), n, vp(s)))
+    reduce(s[2:4])
+    s[0] = s[2]
+    bb = torch.dot(b, b).reshape(1)
+    reduce(bb)
+    h = s[:4].tolist()
+    rr0 = h[3] ** 0.5
+    scale = {"none": 1.0, "initial": rr0 if rr0 > 0 else 1.0, "rhs": max(bb.item() ** 0.5, 1e-300)}[residual_scaling]
+    res, it = rr0 / scale, 0
+    while res > tol and it < max_iters:
+        op.apply(p[None, :], ap[None, :])
+        capi.check(lib.l3k_cg_dot_pap(ctx._h, vp(p), vp(ap), n, vp(s)))
+        reduce(s[1:2])
+        capi.check(lib.l3k_cg_update_xr(ctx._h, vp(x), vp(r), vp(p), vp(ap), vp(minv), n, vp(s)))
+        reduce(s[2:4])
+        res = s[3].item() ** 0.5 / scale
+        capi.check(lib.l3k_cg_update_p(ctx._h, vp(p), vp(r), vp(minv), n, vp(s)))
+        it += 1
+    converged = res <= tol
+    if throw_on_fail and not converged:
+        raise RuntimeError("Solver failed to converge")
+    return IterSolveResult(res, it, converged)

@@ -92,3 +92,33 @@ def test_gpu_pcg_matches_cpu_restatement(kid, ne, p):
     assert np.linalg.norm(x.cpu().numpy() - x_ref.numpy()) < 1e-7 * np.linalg.norm(x_ref.numpy())
     if kid == system.KERNEL_DIFFUSION3D:
         assert np.abs(x.cpu().numpy() - exact).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_native_pcg_matches_torch_pcg():
+    """l3k_pcg_solve (fused HIP vector kernels + the matrix-free apply, all behind the C ABI) and the torch-op PCG give
+    the same iterates: same iteration count (+-1) and the same solution on a Dirichlet problem with a source term."""
+    import torch
+    from l3ster_amd import solve, system
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    p, U = 4, 4
+    part = system.CubePartition(5, p, perturb=0.1)
+    mesh = system.DeviceMesh(ctx, part, U, part.dirichlet_mask(U))
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    diag, rhs = mf.diag_rhs(None)
+    minv = solve.jacobi_inverse_native(ctx, diag)
+    assert torch.equal(minv, solve.jacobi_inverse(diag))
+    x1 = torch.zeros_like(diag)
+    r1 = solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x1, minv, tol=1e-10, residual_scaling="rhs")
+    x2 = torch.zeros_like(diag)
+    r2 = solve.pcg(mf, rhs[0], x2, minv, tol=1e-10, residual_scaling="rhs")
+    assert r2.converged and abs(r1.num_iters - r2.num_iters) <= 1
+    assert (x1 - x2).norm().item() < 1e-8 * x1.norm().item()
+    # the partitioned form of the iteration with a trivial (single-rank) operator
+    class Op:
+        def apply(self, X, Y):
+            mf.apply(X, Y)
+    x3 = torch.zeros_like(diag)
+    r3 = solve.pcg_distributed(Op(), ctx, rhs[0], x3, minv, tol=1e-10, residual_scaling="rhs")
+    assert abs(r3.num_iters - r2.num_iters) <= 1 and (x3 - x2).norm().item() < 1e-8 * x2.norm().item()

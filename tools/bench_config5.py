@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ne", type=int, default=64)
 ap.add_argument("--order", type=int, default=4)
 ap.add_argument("--tol", type=float, default=1e-6)
+ap.add_argument("--check-every", type=int, default=10)
 a = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
@@ -34,21 +35,15 @@ gx, gy, gz = (gid % Nx).double() / (Nx - 1), ((gid // Nx) % Nx).double() / (Nx -
 fields = torch.stack([0.5 * torch.sin(np.pi * gy), 0.25 * torch.cos(np.pi * gx), 0.1 * gz]).contiguous()
 mf.set_fields(fields)
 diag, rhs = mf.diag_rhs(None)  # homogeneous Dirichlet c = 0
-minv = solve.jacobi_inverse(diag)
+minv = solve.jacobi_inverse_native(ctx, diag)
 x = torch.zeros_like(diag)
-n_apply = [0]
-
-
-def apply(v, out):
-    n_apply[0] += 1
-    mf.apply(v[None, :], out[None, :])
-
-
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-res = solve.cg(apply, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000)
+# l3k_pcg_solve: apply + fused vector kernels + reductions behind the C ABI (one 32-byte readback per check)
+res = solve.pcg(mf, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000, check_every=a.check_every)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+n_apply = [res.num_iters + 1]
 dofs = part.n_global_nodes * U
 # apply alone, same operator
 y = torch.empty_like(x)

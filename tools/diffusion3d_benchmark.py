@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ne", type=int, default=6)
 ap.add_argument("--order", type=int, default=6)
 ap.add_argument("--tol", type=float, default=1e-6)
+ap.add_argument("--check-every", type=int, default=10)
 a = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
@@ -38,9 +39,9 @@ mesh = timed("upload_s", lambda: system.DeviceMesh(ctx, part, U, part.dirichlet_
 mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 1.0])
 diag, rhs = timed("diag_rhs_s", lambda: mf.diag_rhs(None))
 x = torch.zeros_like(diag)
-minv = solve.jacobi_inverse(diag)
-res = timed("solve_s", lambda: solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x, minv, tol=a.tol,
-                                        residual_scaling="rhs", max_iters=100000))
+minv = solve.jacobi_inverse_native(ctx, diag)
+res = timed("solve_s", lambda: solve.pcg(mf, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=100000,
+                                         check_every=a.check_every))
 fields = x.view(-1, U).T.contiguous()
 err = timed("error_norm_s", lambda: system.norm_l2(mesh, system.RESIDUAL_DIFFUSION3D_ERROR, fields, kernel_params=[1.0, 1.0]))
 print(json.dumps({"config": f"Diffusion3D benchmark, hex {a.ne}^3, order {p}, Jacobi-PCG rel tol {a.tol}",
