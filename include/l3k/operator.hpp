@@ -232,6 +232,17 @@ public:
     {
         check(l3k_local_assemble(m_mf, first, count, d_K, d_F, d_checksum));
     }
+    // alg_sys.solve(CG{opts, NativeJacobiOpts{}}) for one rank (solve/BelosSolvers.hpp:116-122 + NativePreconditioners.hpp):
+    // d_x holds the initial guess and the result; d_minv from l3k_jacobi_inverse (or nullptr); throws if not converged
+    // like the reference (solve/BelosSolvers.hpp:103)
+    l3k_cg_result solve(const double* d_b, double* d_x, const double* d_minv, l3k_cg_opts opts = {1e-6, 10000, 0, 1}) const
+    {
+        l3k_cg_result res{};
+        check(l3k_pcg_solve(m_mf, d_b, d_x, d_minv, &opts, &res));
+        if (!res.converged)
+            throw std::runtime_error{"Solver failed to converge"};
+        return res;
+    }
     l3k_mf* get() const { return m_mf; }
 
 private:

@@ -149,6 +149,25 @@ int main()
         const auto vol  = l3k::computeIntegral< RobinParams >(dmesh, L3K_RESIDUAL_UNIT3D, nullptr, nullptr, 0);
         std::printf("surface = %.15f, volume = %.15f\n", area[0], vol[0]);
         failures += !(std::fabs(area[0] - 6.) < 1e-12 && std::fabs(vol[0] - 1.) < 1e-13);
+        // endAssembly + solve: diag / rhs, Jacobi, PCG; then |A x - b| / |b| through a fresh apply
+        DevVec diag{n}, rhs{n}, minv{n}, sol{n}, check{n};
+        (void)hipMemset(diag.p, 0, n * sizeof(double));
+        (void)hipMemset(rhs.p, 0, n * sizeof(double));
+        (void)hipMemset(sol.p, 0, n * sizeof(double));
+        sys.diagAndRhs(nullptr, 0, diag.p, rhs.p, n);
+        l3k::check(l3k_jacobi_inverse(ctx.get(), diag.p, int64_t(n), 1., 0., minv.p));
+        const auto res = sys.solve(rhs.p, sol.p, minv.p, {1e-10, 5000, 2, 1});
+        sys.apply(sol.p, n, check.p, n);
+        ctx.synchronize();
+        const auto ax2 = check.down(), b = rhs.down();
+        double     e2 = 0., b2 = 0.;
+        for (size_t i = 0; i < n; ++i)
+        {
+            e2 += (ax2[i] - b[i]) * (ax2[i] - b[i]);
+            b2 += b[i] * b[i];
+        }
+        std::printf("PCG: %d iterations, achieved %.2e, |Ax-b|/|b| = %.2e\n", res.iterations, res.achieved_tol, std::sqrt(e2 / b2));
+        failures += !(std::sqrt(e2 / b2) < 1e-9);
     }
     try
     { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)
