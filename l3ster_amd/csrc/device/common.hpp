@@ -9,6 +9,14 @@
 
 #include "l3k/kernel_interface.hpp"
 
+// Ablation switches (tools/kbench.py) exist only in a library built with L3K_ABLATION=1 (python -m l3ster_amd.build
+// with that variable set writes lib/libl3k_ablation.so); in the product build they fold away at compile time.
+#ifdef L3K_ABLATION
+#define L3K_DBG(a) ((a).dbg)
+#else
+#define L3K_DBG(a) 0
+#endif
+
 namespace l3k::dev
 {
 inline constexpr int max_unknowns = 8;
@@ -76,7 +84,7 @@ struct ElemArgs
     int64_t elem_begin_out; // output slot of the first element of the batch
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
-    int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS); 0 in production
+    int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
     // boundary terms / integrals: element sides [face_begin, face_begin + face_count) of the list (device arrays)
     const int64_t* face_elem;
     const uint8_t* face_side;

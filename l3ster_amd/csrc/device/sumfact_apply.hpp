@@ -282,7 +282,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
             if constexpr (RHS_MODE)
                 val = (dir && a.dirichlet_vals) ? a.dirichlet_vals[dof + a.ldg * r] : 0.;
             else
-                val = (a.dbg & 2) ? double(t) * 1e-3 : (dir ? 0. : (dof < a.n_owned_dofs ? a.x[dof + a.ldx * r] : a.xg[(dof - a.n_owned_dofs) + a.ldxg * r]));
+                val = (L3K_DBG(a) & 2) ? double(t) * 1e-3 : (dir ? 0. : (dof < a.n_owned_dofs ? a.x[dof + a.ldx * r] : a.xg[(dof - a.n_owned_dofs) + a.ldxg * r]));
             B0[(r * U + u) * M3 + i] = val;
         }
     }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     __syncthreads();
 
     // ---- interpolation to the Gauss points: x, y, z sweeps
-    if (!(a.dbg & 8))
+    if (!(L3K_DBG(a) & 8))
     {
     sweep< 0, N1, NQ, false, false, N1, N1, N1, NF, NT >(B0, B1, M3, tabI, tid); // -> (NQ, N1, N1)
     __syncthreads();
@@ -311,7 +311,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     }
 
     // ---- quadrature points: one per thread
-    if (!(a.dbg & 4))
+    if (!(L3K_DBG(a) & 4))
     for (int q = tid; q < NQP; q += NT)
     {
         const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     __syncthreads();
 
     // ---- transposed collocation derivatives accumulate into the value array
-    if (!(a.dbg & 8))
+    if (!(L3K_DBG(a) & 8))
     {
     sweep< 0, NQ, NQ, true, true, NQ, NQ, NQ, OPS, NT >(B2, B1, M3, tabC, tid);
     __syncthreads();
@@ -378,7 +378,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
                     a.F[((e - a.elem_begin) + a.elem_begin_out) * int64_t(NN * U) * RT + (i * U + u) + int64_t(NN * U) * (C0 + r)] = val;
                     continue;
                 }
-            if (a.dbg & 1)
+            if (L3K_DBG(a) & 1)
             {
                 if (val == 1.2345e300)
                     *dst = val;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
                 *dst = (dir ? 0. : val) + (a.beta == 0. ? 0. : a.beta * *dst);
             else if (!dir)
             {
-                if (a.dbg & 16)
+                if (L3K_DBG(a) & 16)
                     *dst = val;
                 else
                     unsafeAtomicAdd(dst, val);

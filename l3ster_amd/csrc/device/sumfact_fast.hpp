@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
 #pragma unroll
             for (int hh = 0; hh < U / 2; ++hh)
             {
-                const double2 t = (a.dbg & 2) ? make_double2(1e-9 * double(node), 1e-9)
+                const double2 t = (L3K_DBG(a) & 2) ? make_double2(1e-9 * double(node), 1e-9)
                                               : *reinterpret_cast< const double2* >(p + 2 * hh);
                 xn[k][2 * hh]     = t.x;
                 xn[k][2 * hh + 1] = t.y;
@@ -255,7 +255,8 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
 
     for (; batch < last; batch += stride)
     {
-        const bool act = (int64_t(batch) * EW + team) < a.elem_count; // this team has an element in this batch
+        // this team has an element in this batch (always, with one element per wave: batch < last <= elem_count)
+        const bool act = (int64_t(batch) * EW + team) < a.elem_count;
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                     const double2 val  = sb2[t];
                     const bool    d0   = flagged && a.dirichlet[dof] != 0, d1 = flagged && a.dirichlet[dof + 1] != 0;
                     double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                    if (a.dbg & 1)
+                    if (L3K_DBG(a) & 1)
                     {
                         if (val.x == 1.2345e300)
                             *dst = val.x;
@@ -657,22 +658,22 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                     }
                     else
                     {
-                        if (a.dbg & 96) // ablation: 32 = plain 16-byte store instead of the atomics, 64 = no memory operation
+                        if (L3K_DBG(a) & 96) // ablation: 32 = plain 16-byte store instead of the atomics, 64 = no memory operation
                         {
-                            if ((a.dbg & 32) || val.x == 1.2345e300)
+                            if ((L3K_DBG(a) & 32) || val.x == 1.2345e300)
                                 *reinterpret_cast< double2* >(dst) = val;
                             continue;
                         }
                         if (!d0)
                         {
-                            if (a.dbg & 16)
+                            if (L3K_DBG(a) & 16)
                                 dst[0] += val.x;
                             else
                                 unsafeAtomicAdd(dst, val.x);
                         }
                         if (!d1)
                         {
-                            if (a.dbg & 16)
+                            if (L3K_DBG(a) & 16)
                                 dst[1] += val.y;
                             else
                                 unsafeAtomicAdd(dst + 1, val.y);
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                     const bool    dir  = flagged && a.dirichlet[dof] != 0;
                     const double  val  = sb[t];
                     double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                    if (a.dbg & 1)
+                    if (L3K_DBG(a) & 1)
                     {
                         if (val == 1.2345e300)
                             *dst = val;
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
                         *dst = (dir ? 0. : val) + (a.beta == 0. ? 0. : a.beta * *dst);
                     else if (!dir)
                     {
-                        if (a.dbg & 16)
+                        if (L3K_DBG(a) & 16)
                             *dst += val;
                         else
                             unsafeAtomicAdd(dst, val);

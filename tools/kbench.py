@@ -52,5 +52,10 @@ if __name__ == "__main__":
     else:
         for f in a.flags.split(","):
             env = dict(os.environ, L3K_DEBUG_FLAGS=f)
+            if f != "0":  # ablation switches live in the L3K_ABLATION=1 build only
+                lib = os.path.join(ROOT, "l3ster_amd", "lib", "libl3k_ablation.so")
+                if not os.path.exists(lib):
+                    raise SystemExit("build the ablation library first: L3K_ABLATION=1 python -m l3ster_amd.build")
+                env["L3K_LIB"] = lib
             subprocess.run([sys.executable, __file__, "--child", "--order", str(a.order), "--ne", str(a.ne), "--steps",
                             str(a.steps), "--perturb", str(a.perturb)], env=env, check=True)
