@@ -118,9 +118,11 @@ struct GemmCfg
     static constexpr int BT  = 128;                        // tile edge
     static constexpr int NTL = (ND + BT - 1) / BT;         // tiles per edge
     static constexpr int NLT = NTL * (NTL + 1) / 2;        // lower-triangular tiles
-    static constexpr int KC  = 16;                         // K chunk (4 MFMA k-steps)
+    static constexpr int QC  = 4;                          // quadrature points per K chunk
+    static constexpr int KC  = QC * E;                     // K chunk: a multiple of the MFMA k-step 4 for every E
     static constexpr int LDS_ROW = BT + 16;                // +16 doubles: rows k and k+1 land in disjoint bank halves
-    static constexpr size_t lds = sizeof(double) * (2 * KC * LDS_ROW + 2 * N1 * NQ);
+    static constexpr int CSP = ((4 * E * U + 1) + 1) & ~1; // coefficient record padded to an even number of doubles
+    static constexpr size_t lds = sizeof(double) * (2 * KC * LDS_ROW + QC * CSP + 2 * N1 * NQ);
 };
 
 template < typename K, int P, int NQ >
@@ -129,14 +131,15 @@ __global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, cons
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = GemmCfg< P, NQ, U, E >;
-    constexpr int         N1 = C::N1, ND = C::ND, NQP = C::NQP, KD = C::KD, KC = C::KC, BT = C::BT, LR = C::LDS_ROW;
+    constexpr int         N1 = C::N1, ND = C::ND, NQP = C::NQP, KC = C::KC, QC = C::QC, BT = C::BT, LR = C::LDS_ROW, CSP = C::CSP;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
 
     extern __shared__ double lds[];
     double* const            ZA = lds;                 // [KC][LR]: w*detJ * Z for the tile's rows (A operand)
     double* const            ZB = ZA + KC * LR;        // [KC][LR]: Z for the tile's columns (B operand)
-    double* const            tI = ZB + KC * LR;        // [N1][NQ]
+    double* const            cs = ZB + KC * LR;        // [QC][CSP]: coefficient records of the chunk's quadrature points
+    double* const            tI = cs + QC * CSP;       // [N1][NQ]
     double* const            tD = tI + N1 * NQ;
 
     const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -153,8 +156,8 @@ __global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, cons
     for (int i = tid; i < 2 * N1 * NQ; i += 256)
         tI[i] = a.tables[(i < N1 * NQ ? TL.offI() : TL.offD() - N1 * NQ) + i];
 
-    // this thread generates Z entries of one fixed column of each panel: decode (b, u) once
-    const int  col  = tid & (BT - 1), kr0 = tid >> 7; // kr = kr0 + 2*j
+    // this thread generates the Z entries of one fixed column of each panel for QC/2 quadrature points of every chunk
+    const int  col  = tid & (BT - 1), half = tid >> 7;
     const int  ga = ti * BT + col, gb = tj * BT + col;
     const bool va = ga < ND, vb = gb < ND;
     const int  ba = va ? ga / U : 0, ua = va ? ga % U : 0, bb = vb ? gb / U : 0, ub = vb ? gb % U : 0;
@@ -167,42 +170,63 @@ __global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[i][j] = mfma_d4{0., 0., 0., 0.};
-    __syncthreads();
 
     const double* cel = cbuf + el * NQP * CS;
-    for (int k0 = 0; k0 < KD; k0 += KC)
+    for (int q0 = 0; q0 < NQP; q0 += QC)
     {
-        // ---- generate the two Z chunks
-#pragma unroll
-        for (int j = 0; j < KC / 2; ++j)
+        // ---- stage the chunk's coefficient records (contiguous in the workspace) in LDS
+        for (int i = tid; i < QC * CS; i += 256)
         {
-            const int kr = kr0 + 2 * j, kk = k0 + kr;
-            double    za = 0., zb = 0.;
-            if (kk < KD)
-            {
-                const int     q = kk / E, e_ = kk - q * E;
-                const int     qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-                const double* cq = cel + q * CS;
-                if (va)
-                {
-                    const double  ix = tI[bax * NQ + qx], iy = tI[bay * NQ + qy], iz = tI[baz * NQ + qz];
-                    const double  dx = tD[bax * NQ + qx], dy = tD[bay * NQ + qy], dz = tD[baz * NQ + qz];
-                    const double* c  = cq + (e_ * U + ua) * 4;
-                    za = (c[0] * ix * iy * iz + c[1] * dx * iy * iz + c[2] * ix * dy * iz + c[3] * ix * iy * dz) * cq[CS - 1];
-                }
-                if (vb)
-                {
-                    const double  ix = tI[bbx * NQ + qx], iy = tI[bby * NQ + qy], iz = tI[bbz * NQ + qz];
-                    const double  dx = tD[bbx * NQ + qx], dy = tD[bby * NQ + qy], dz = tD[bbz * NQ + qz];
-                    const double* c  = cq + (e_ * U + ub) * 4;
-                    zb = c[0] * ix * iy * iz + c[1] * dx * iy * iz + c[2] * ix * dy * iz + c[3] * ix * iy * dz;
-                }
-            }
-            ZA[kr * LR + col] = za;
-            ZB[kr * LR + col] = zb;
+            const int qi = i / CS, r = i - qi * CS;
+            cs[qi * CSP + r] = q0 + qi < NQP ? cel[int64_t(q0) * CS + i] : 0.;
         }
         __syncthreads();
-        // ---- 4 k-steps of 16 MFMAs: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
+        // ---- generate the two Z chunks: the basis products of (column, q) once, then 4 FMAs per equation
+#pragma unroll
+        for (int s = 0; s < QC / 2; ++s)
+        {
+            const int qi = half * (QC / 2) + s, q = q0 + qi;
+            if (q < NQP)
+            {
+                const int     qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+                const double* cq = cs + qi * CSP;
+                const double  w  = cq[CS - 1];
+                double        pa[4], pb[4];
+                {
+                    const double ix = tI[bax * NQ + qx], iy = tI[bay * NQ + qy], iz = tI[baz * NQ + qz];
+                    const double dx = tD[bax * NQ + qx], dy = tD[bay * NQ + qy], dz = tD[baz * NQ + qz];
+                    const double yz = iy * iz * w, xw = ix * w;
+                    pa[0] = ix * yz, pa[1] = dx * yz, pa[2] = xw * dy * iz, pa[3] = xw * iy * dz;
+                }
+                {
+                    const double ix = tI[bbx * NQ + qx], iy = tI[bby * NQ + qy], iz = tI[bbz * NQ + qz];
+                    const double dx = tD[bbx * NQ + qx], dy = tD[bby * NQ + qy], dz = tD[bbz * NQ + qz];
+                    const double yz = iy * iz;
+                    pb[0] = ix * yz, pb[1] = dx * yz, pb[2] = ix * dy * iz, pb[3] = ix * iy * dz;
+                }
+#pragma unroll
+                for (int e_ = 0; e_ < E; ++e_)
+                {
+                    const double* ca = cq + (e_ * U + ua) * 4;
+                    const double* cb = cq + (e_ * U + ub) * 4;
+                    const double  za = ca[0] * pa[0] + ca[1] * pa[1] + ca[2] * pa[2] + ca[3] * pa[3];
+                    const double  zb = cb[0] * pb[0] + cb[1] * pb[1] + cb[2] * pb[2] + cb[3] * pb[3];
+                    ZA[(qi * E + e_) * LR + col] = va ? za : 0.;
+                    ZB[(qi * E + e_) * LR + col] = vb ? zb : 0.;
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int e_ = 0; e_ < E; ++e_)
+                {
+                    ZA[(qi * E + e_) * LR + col] = 0.;
+                    ZB[(qi * E + e_) * LR + col] = 0.;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- KC/4 k-steps of 16 MFMAs: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]
 #pragma unroll
         for (int ks = 0; ks < KC / 4; ++ks)
         {
@@ -220,12 +244,12 @@ __global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, cons
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        // the next chunk's staging writes `cs` only; Z is rewritten after the barrier that follows the staging
     }
 
     // ---- epilogue: C/D layout of the f64 MFMA: row = (lane>>4) + 4*reg, col = lane&15
     double* Kel = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
-    double  cs  = 0.;
+    double  csum = 0.;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -246,18 +270,18 @@ __global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, cons
                         if (gi != gj)
                             Kel[int64_t(gj) * ND + gi] = v;
                     }
-                    cs += v * (1 + ((gi * 31 + gj * 17) % 7));
+                    csum += v * (1 + ((gi * 31 + gj * 17) % 7));
                     if (gi != gj)
-                        cs += v * (1 + ((gj * 31 + gi * 17) % 7));
+                        csum += v * (1 + ((gj * 31 + gi * 17) % 7));
                 }
             }
     if (a.checksum)
     {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
-            cs += __shfl_down(cs, off);
+            csum += __shfl_down(csum, off);
         if (lane == 0)
-            unsafeAtomicAdd(a.checksum + elem0 + el, cs);
+            unsafeAtomicAdd(a.checksum + elem0 + el, csum);
     }
 }
 
