@@ -79,7 +79,8 @@ enum
 {
     L3K_RESIDUAL_DIFFUSION3D_ERROR = 0, /* benchmarks/Diffusion3D.hpp:81-103; fields (T,qx,qy,qz); params {double k, s} */
     L3K_RESIDUAL_LINEAR3D_ERROR    = 2, /* 3-D twin of tests/Diffusion2D.hpp:84-92: error against T = x, q = (1,0,0)   */
-    L3K_RESIDUAL_UNIT3D            = 4  /* tests/MappingTests.cpp:567-569: integrand 1                                */
+    L3K_RESIDUAL_UNIT3D            = 4, /* tests/MappingTests.cpp:567-569: integrand 1                                */
+    L3K_RESIDUAL_COORDX3D          = 6  /* 3-D twin of tests/Diffusion2D.hpp:49-50: out[0] = x (Dirichlet value kernel) */
 };
 int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_t* param_bytes);
 /* number of (kernel, order, nq, ncols) device instantiations, and the i-th one: for "is this shape built?" queries */
@@ -197,6 +198,19 @@ int l3k_residual_info(int residual_id, l3k_kparams* params, const char** name, s
 int l3k_integrate(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
                   const l3k_asmopts* opts, const double* d_fields, size_t ldf, double time, int square, int64_t n_faces,
                   const int64_t* face_elem, const uint8_t* face_side, double* h_out);
+
+/* ---- values of residual kernels at the nodes (Dirichlet values, initial conditions) ---------------------------------------
+ * computeValuesAtNodes (algsys/ComputeValuesAtNodes.hpp:371-448 domain, :508-594 boundary), the engine behind
+ * setDirichletBCValues / setValues: the kernel is evaluated at the nodes of the listed element sides (n_faces >= 0) or of
+ * every element (n_faces < 0) with the nodal field values, their physical derivatives, the point and (sides) the outward
+ * normal; equation e is ADDED to d_sum[node * dofs_per_node + dof_inds[e]] and 1 to d_count[...] (both over all local
+ * dofs, owned then ghost; the caller zeroes them, and in a partitioned run exports the ghost rows of both to their owners
+ * before averaging).  l3k_average_values: values[i] = sum[i] / count[i] where count[i] > 0, other entries untouched
+ * (averageElementContributions :112-154). */
+int l3k_values_at_nodes(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
+                        const double* d_fields, size_t ldf, double time, int64_t n_faces, const int64_t* face_elem,
+                        const uint8_t* face_side, const int* dof_inds, double* d_sum, double* d_count);
+int l3k_average_values(l3k_ctx* ctx, const double* d_sum, const double* d_count, int64_t n, double* d_values);
 
 /* ---- Jacobi-preconditioned conjugate gradients ------------------------------------------------------------------------
  * The reference hands the iteration to Trilinos Belos ("Block CG", solve/BelosSolvers.hpp:116-122) with its native Jacobi

@@ -94,6 +94,9 @@ SIGNATURES = {
     "l3k_residual_info": (C.c_int, [C.c_int, C.POINTER(KParams), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
     "l3k_integrate": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), _vp, C.c_size_t, C.c_double,
                                 C.c_int, C.c_int64, c_int64_p, c_uint8_p, c_double_p]),
+    "l3k_values_at_nodes": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_double, C.c_int64, c_int64_p,
+                                      c_uint8_p, c_int_p, _vp, _vp]),
+    "l3k_average_values": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "l3k_jacobi_inverse": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, C.c_double, _vp]),
     "l3k_pcg_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(CgOpts), C.POINTER(CgResult)]),
     "l3k_cg_init": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),

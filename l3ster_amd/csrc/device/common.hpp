@@ -45,7 +45,8 @@ struct TableLayout
     constexpr int offID() const { return offII() + n * nq; }
     constexpr int offDD() const { return offID() + n * nq; }
     constexpr int offE() const { return offDD() + n * nq; } // phi_k'(-1) [n] | phi_k'(+1) [n] (boundary kernels)
-    constexpr int size() const { return offE() + 2 * n; }
+    constexpr int offDG() const { return offE() + 2 * n; }  // phi_b'(gll_q), [b][q], n x n (values at the nodes)
+    constexpr int size() const { return offDG() + n * n; }
 };
 
 // Everything an element kernel needs; passed by value as the kernel argument (scalar loads).
@@ -91,6 +92,8 @@ struct ElemArgs
     int64_t        face_begin, face_count;
     double*        partial; // integrals: [n_blocks][E] per-block partial sums
     int            square;  // integrate the squared residual (L2 norm)
+    double*        node_sum;   // values at nodes: [n_local_dofs] accumulated kernel values ...
+    double*        node_count; // ... and number of contributions
 };
 
 using LaunchFn = int (*)(const ElemArgs&, const void* kparam_blob, hipStream_t stream);
@@ -116,6 +119,7 @@ struct IntegralInstance
 {
     int      residual_id, order, nq;
     LaunchFn domain, boundary;
+    LaunchFn at_nodes; // computeValuesAtNodes (independent of nq; registered with every instance of the kernel / order)
 };
 void                    registerBoundaryInstance(const BoundaryInstance& inst);
 const BoundaryInstance* findBoundaryInstance(int kernel_id, int order, int nq, int ncols);

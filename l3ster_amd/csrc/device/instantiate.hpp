@@ -84,7 +84,8 @@ constexpr LaunchFn selectApply()
         {                                                                                                              \
             ::l3k::dev::registerIntegralInstance({::l3k::dev::ResidualId< T >::value, P, NQ,                           \
                                                   &::l3k::dev::launchIntegral< T, P, NQ, false >,                      \
-                                                  &::l3k::dev::launchIntegral< T, P, NQ, true >});                     \
+                                                  &::l3k::dev::launchIntegral< T, P, NQ, true >,                       \
+                                                  &::l3k::dev::launchValuesAtNodesAny< T, P, NQ >});                   \
         }                                                                                                              \
     } L3K_CAT(rregistrar_, __LINE__);                                                                                  \
     }

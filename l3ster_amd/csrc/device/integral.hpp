@@ -266,6 +266,120 @@ __global__ __launch_bounds__(integral_threads) void integralSideKernel(const Ele
     blockReduceStore< E >(acc, red, a.partial + int64_t(blockIdx.x) * E);
 }
 
+// computeValuesAtNodes (algsys/ComputeValuesAtNodes.hpp:371-448 domain, :508-594 boundary): the residual kernel evaluated
+// AT THE NODES of an element side (or of the whole element): field values are the nodal values, reference derivatives
+// come from the GLL differentiation matrix phi_b'(gll_q); equation e is accumulated into dof field_inds[e] of the node
+// together with a contribution count; l3k_average_values divides (averageElementContributions :112-154).
+template < typename K, int P, int NQ, bool SIDE >
+__global__ __launch_bounds__(integral_threads) void valuesAtNodesKernel(const ElemArgs a, const K kern)
+{
+    constexpr KernelParams params = K::params;
+    constexpr int          E = params.n_equations, F = params.n_fields, FA = F > 0 ? F : 1;
+    constexpr int          N1 = P + 1, NN = N1 * N1 * N1, N2 = N1 * N1, NT = integral_threads;
+    constexpr TableLayout  TL{N1, NQ};
+    using Iface = KernelInterface< params >;
+
+    extern __shared__ double lds[];
+    double* const            xs = lds;            // [F][NN]
+    double* const            vs = xs + FA * NN;   // [8][3]
+
+    const int       tid  = threadIdx.x;
+    const int64_t   f    = SIDE ? a.face_begin + blockIdx.x : 0;
+    const int64_t   e    = SIDE ? a.face_elem[f] : a.elem_begin + blockIdx.x;
+    const SideAxes  sa   = sideAxes(SIDE ? a.face_side[f] : 0);
+    const uint32_t* en   = a.elem_nodes + e * NN;
+    const double*   gll  = a.tables + TL.offG();
+    const double*   tabG = a.tables + TL.offDG();
+    if (tid < 24)
+        vs[tid] = a.elem_verts[e * 24 + tid];
+    for (int t = tid; t < NN * F; t += NT)
+    {
+        const int fl = t / NN, i = t - fl * NN;
+        xs[fl * NN + i] = a.fields[en[i] + fl * a.ldf];
+    }
+    __syncthreads();
+    const int str[3] = {1, N1, N2};
+    for (int t = tid; t < (SIDE ? N2 : NN); t += NT)
+    {
+        int c[3];
+        if constexpr (SIDE) // getSideNodeInds: the normal coordinate sits at the side's end
+        {
+            c[sa.t1] = t % N1;
+            c[sa.t2] = t / N1;
+            c[sa.n]  = sa.upper ? P : 0;
+        }
+        else
+        {
+            c[0] = t % N1, c[1] = (t / N1) % N1, c[2] = t / N2;
+        }
+        const int i = c[0] + N1 * c[1] + N2 * c[2];
+        double    G[6][3], Jm[3][3], Ji[3][3], xyz[3], nrm[3] = {0., 0., 0.};
+        if constexpr (SIDE)
+            sidePointGeom(vs, sa, gll[c[sa.t1]], gll[c[sa.t2]], Jm, Ji, xyz, nrm);
+        else
+        {
+            hexPencilGeom(vs, gll[c[1]], gll[c[2]], G);
+            hexPointOnPencil(G, gll[c[0]], Jm, xyz);
+            inverse3(Jm, Ji);
+        }
+        typename Iface::BoundaryInput in;
+#pragma unroll
+        for (int fl = 0; fl < F; ++fl)
+        {
+            const double* xf = xs + fl * NN;
+            in.field_vals[fl] = xf[i];
+            double dr[3] = {0., 0., 0.};
+            for (int d = 0; d < 3; ++d)
+                for (int b = 0; b < N1; ++b)
+                    dr[d] += tabG[b * N1 + c[d]] * xf[i + (b - c[d]) * str[d]];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                in.field_ders[s][fl] = Ji[0][s] * dr[0] + Ji[1][s] * dr[1] + Ji[2][s] * dr[2];
+        }
+        in.point  = SpaceTimePoint{Point3{{xyz[0], xyz[1], xyz[2]}}, a.time};
+        in.normal = {{nrm[0], nrm[1], nrm[2]}};
+        typename Iface::Rhs out{};
+        kern(in, out);
+        const int64_t node = en[i];
+#pragma unroll
+        for (int eq = 0; eq < E; ++eq)
+        {
+            const int64_t dof = node * a.dofs_per_node + a.field_inds[eq];
+            unsafeAtomicAdd(a.node_sum + dof, out[eq]);
+            unsafeAtomicAdd(a.node_count + dof, 1.);
+        }
+    }
+}
+
+template < typename K, int P, int NQ, bool SIDE >
+int launchValuesAtNodes(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    const int64_t count = SIDE ? a.face_count : a.elem_count;
+    if (count <= 0)
+        return 0;
+    constexpr int    FA  = K::params.n_fields > 0 ? K::params.n_fields : 1;
+    constexpr size_t lds = sizeof(double) * (size_t(FA) * (P + 1) * (P + 1) * (P + 1) + 24);
+    K kern{};
+    if (kparam_blob)
+        __builtin_memcpy(&kern, kparam_blob, sizeof(K));
+    hipLaunchKernelGGL((valuesAtNodesKernel< K, P, NQ, SIDE >), dim3(static_cast< unsigned >(count)), dim3(integral_threads), lds,
+                       stream, a, kern);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+    {
+        setError("valuesAtNodesKernel launch failed: %s", hipGetErrorString(err));
+        return -3;
+    }
+    return 0;
+}
+// side = a.face_count > 0 selects the boundary form
+template < typename K, int P, int NQ >
+int launchValuesAtNodesAny(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    return a.face_elem ? launchValuesAtNodes< K, P, NQ, true >(a, kparam_blob, stream)
+                       : launchValuesAtNodes< K, P, NQ, false >(a, kparam_blob, stream);
+}
+
 template < typename K, int P, int NQ, bool SIDE >
 int launchIntegral(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
 {

@@ -46,7 +46,7 @@ void registerIntegralInstance(const IntegralInstance& inst)
 const IntegralInstance* findIntegralInstance(int residual_id, int order, int nq)
 {
     for (const auto& i : integralTable())
-        if (i.residual_id == residual_id && i.order == order && i.nq == nq)
+        if (i.residual_id == residual_id && i.order == order && (nq < 0 || i.nq == nq)) // nq < 0: any (values at nodes)
             return &i;
     return nullptr;
 }

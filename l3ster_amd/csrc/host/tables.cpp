@@ -216,6 +216,15 @@ std::vector< double > deviceTableBlock(int p, int nq)
         lagrange(gll, x, v.data(), d.data());
         out.insert(out.end(), d.begin(), d.end());
     }
+    // derivative of the basis at the nodes themselves, [b][q] = phi_b'(gll_q) (computeValuesAtNodes)
+    std::vector< double > dg(size_t(n) * n);
+    for (int q = 0; q < n; ++q)
+    {
+        lagrange(gll, gll[q], v.data(), d.data());
+        for (int b = 0; b < n; ++b)
+            dg[size_t(b) * n + q] = d[b];
+    }
+    out.insert(out.end(), dg.begin(), dg.end());
     return out;
 }
 } // namespace l3k::host

@@ -192,6 +192,17 @@ struct Linear3DError
         error[3]         = vals[3];
     }
 };
+// 3-D twin of the Dirichlet value kernel of tests/Diffusion2D.hpp:49-50: out[0] = x
+struct CoordX3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        out[0] = in.point.space.x();
+    }
+};
 // tests/MappingTests.cpp:567-569: integrand 1 (volume / area)
 struct Unit3D
 {
@@ -220,7 +231,8 @@ struct Unit3D
 #define L3K_FOR_EACH_RESIDUAL_KERNEL(X)                                                                                \
     X(0, ::l3k::kernels::Diffusion3DError, "diffusion3d_error")                                                        \
     X(2, ::l3k::kernels::Linear3DError, "linear3d_error")                                                              \
-    X(4, ::l3k::kernels::Unit3D, "unit3d")
+    X(4, ::l3k::kernels::Unit3D, "unit3d")                                                                             \
+    X(6, ::l3k::kernels::CoordX3D, "coordx3d")
 
 // Shapes instantiated on the device: (functor, order p, quadrature points per direction nq, columns R).
 // nq = value_order*p + derivative_order*(p-1) + 1 (algsys/AssembleLocalSystem.hpp:32-35).
@@ -260,6 +272,9 @@ struct Unit3D
     X(::l3k::kernels::Linear3DError, 4, 9)                                                                             \
     X(::l3k::kernels::Unit3D, 1, 6)                                                                                    \
     X(::l3k::kernels::Unit3D, 2, 3)                                                                                    \
-    X(::l3k::kernels::Unit3D, 2, 5)
+    X(::l3k::kernels::Unit3D, 2, 5)                                                                                    \
+    X(::l3k::kernels::CoordX3D, 2, 3)                                                                                  \
+    X(::l3k::kernels::CoordX3D, 4, 5)                                                                                  \
+    X(::l3k::kernels::CoordX3D, 6, 7)
 
 #endif

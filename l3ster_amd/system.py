@@ -24,6 +24,7 @@ KERNEL_ROBIN3D = 7
 RESIDUAL_DIFFUSION3D_ERROR = 0
 RESIDUAL_LINEAR3D_ERROR = 2
 RESIDUAL_UNIT3D = 4
+RESIDUAL_COORDX3D = 6
 
 
 # ------------------------------------------------------------------------------------------------------- tables
@@ -337,6 +338,32 @@ def integrate(mesh, residual_id, fields=None, kernel_params=None, asm_opts=(1, 0
                                     0 if fields is None else fields.shape[1], float(time), int(square), nf, fe_p, fs_p,
                                     out.ctypes.data_as(capi.c_double_p)))
     return out
+
+
+def values_at_nodes(mesh, residual_id, dof_inds, values, fields=None, kernel_params=None, time=0.0, face_elem=None,
+                    face_side=None):
+    """computeValuesAtNodes (algsys/ComputeValuesAtNodes.hpp) on one rank -- the engine of setDirichletBCValues / setValues:
+    evaluates the residual kernel at the nodes of the listed element sides (or of all elements), averages the
+    contributions per dof and writes them into `values` (1-D device tensor over the local dofs); other entries keep their
+    content.  Returns `values`."""
+    import torch
+    info = residual_info(residual_id)
+    if len(dof_inds) != info["n_equations"]:
+        raise L3KError("one dof index per equation of the kernel")
+    blob, nbytes, keep = _blob(kernel_params)
+    di = (C.c_int * len(dof_inds))(*dof_inds)
+    s = torch.zeros_like(values)
+    c = torch.zeros_like(values)
+    if face_elem is None:
+        nf, fe_p, fs_p = -1, None, None
+    else:
+        fe, fs = _sides(face_elem, face_side)
+        nf, fe_p, fs_p = fe.size, fe.ctypes.data_as(capi.c_int64_p), fs.ctypes.data_as(capi.c_uint8_p)
+    lib = capi.load()
+    check(lib.l3k_values_at_nodes(mesh.ctx._h, mesh._h, residual_id, blob, nbytes, _ptr(fields),
+                                  0 if fields is None else fields.shape[1], float(time), nf, fe_p, fs_p, di, _ptr(s), _ptr(c)))
+    check(lib.l3k_average_values(mesh.ctx._h, _ptr(s), _ptr(c), values.numel(), _ptr(values)))
+    return values
 
 
 def norm_l2(mesh, residual_id, fields=None, kernel_params=None, asm_opts=(1, 0, 0), time=0.0, face_elem=None,

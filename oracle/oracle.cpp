@@ -804,6 +804,11 @@ void rUnit(const KIn&, double* e)
 {
     e[0] = 1.;
 }
+// tests/Diffusion2D.hpp:49-50: Dirichlet value kernel out[0] = x (node_dist.back() == 1)
+void rCoordX(const KIn& in, double* e)
+{
+    e[0] = in.x;
+}
 struct ResidualEntry
 {
     int  dim, E, F;
@@ -812,7 +817,7 @@ struct ResidualEntry
 const ResidualEntry* getResidual(int id)
 {
     static const ResidualEntry table[] = {{3, 4, 4, rDiffusion3DError}, {2, 3, 3, rLinear2DError}, {3, 4, 4, rLinear3DError},
-                                          {2, 1, 0, rUnit}, {3, 1, 0, rUnit}};
+                                          {2, 1, 0, rUnit}, {3, 1, 0, rUnit}, {2, 1, 0, rCoordX}, {3, 1, 0, rCoordX}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];
@@ -1853,6 +1858,87 @@ int orc_bnd_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, do
                 for (int r = 0; r < R; ++r)
                     rhs[dof + ldr * r] += lrhs[(n * U + u) + static_cast< size_t >(Nd) * r];
             }
+    }
+    return 0;
+}
+
+// computeValuesAtNodes for residual kernels (algsys/ComputeValuesAtNodes.hpp:371-448 domain, :508-594 boundary): the kernel
+// is evaluated AT THE NODES (reference basis at the node locations, basisfun/ReferenceBasisAtNodes.hpp:10-19) of every
+// listed element side (n_faces >= 0) or of every element (n_faces < 0); equation e goes to dof dof_inds[e] of the node;
+// sum[dof] += value, count[dof] += 1 per visit.  The caller averages (averageElementContributions :112-154: sum / count
+// where count > 0, other entries keep their value).
+int orc_values_at_nodes(const orc_mesh* m, int residual_id, const double* kparams, double time, int64_t n_faces,
+                        const int64_t* face_elem, const uint8_t* face_side, const int* dof_inds, double* sum, double* count)
+{
+    const auto* r = getResidual(residual_id);
+    if (!r)
+        return fail(-1, "unknown residual kernel id");
+    if (r->dim != m->dim)
+        return fail(-1, "kernel / mesh dimension mismatch");
+    const int dim = m->dim, p = m->p, n = p + 1, N = ipow(n, dim), nv = 1 << dim, F = r->F, dpn = m->dofs_per_node;
+    // reference basis at the nodes: values = identity, derivatives from the 1-D Lagrange basis at the GLL points
+    const auto gll = gllNodes(n);
+    RefBasis   rb;
+    rb.dim = dim, rb.N = N, rb.nqp = N;
+    rb.vals.assign(static_cast< size_t >(N) * N, 0.);
+    rb.ders.assign(static_cast< size_t >(N) * dim * N, 0.);
+    rb.weights.assign(N, 0.);
+    rb.points.assign(static_cast< size_t >(N) * dim, 0.);
+    std::vector< double > v1(static_cast< size_t >(n) * n), d1(static_cast< size_t >(n) * n); // [point][basis]
+    for (int q = 0; q < n; ++q)
+        lagrange1d(gll, gll[q], &v1[static_cast< size_t >(q) * n], &d1[static_cast< size_t >(q) * n]);
+    for (int pt = 0; pt < N; ++pt)
+    {
+        const int pi[3] = {pt % n, (pt / n) % n, pt / (n * n)};
+        for (int a = 0; a < dim; ++a)
+            rb.points[pt * dim + a] = gll[pi[a]];
+        for (int b = 0; b < N; ++b)
+        {
+            const int bi[3] = {b % n, (b / n) % n, b / (n * n)};
+            double    val   = 1.;
+            for (int a = 0; a < dim; ++a)
+                val *= v1[pi[a] * n + bi[a]];
+            rb.vals[static_cast< size_t >(pt) * N + b] = val;
+            for (int dd = 0; dd < dim; ++dd)
+            {
+                double dv = 1.;
+                for (int a = 0; a < dim; ++a)
+                    dv *= (a == dd) ? d1[pi[a] * n + bi[a]] : v1[pi[a] * n + bi[a]];
+                rb.ders[(static_cast< size_t >(pt) * dim + dd) * N + b] = dv;
+            }
+        }
+    }
+    std::vector< double > nf(static_cast< size_t >(N) * std::max(F, 1)), scratch, val(r->E);
+    QpData                qd;
+    const int64_t         cnt = n_faces < 0 ? m->n_elems : n_faces;
+    for (int64_t i = 0; i < cnt; ++i)
+    {
+        const int64_t   el    = n_faces < 0 ? i : face_elem[i];
+        const int       side  = n_faces < 0 ? -1 : face_side[i];
+        const uint32_t* nodes = m->elem_nodes + el * N;
+        for (int b = 0; b < N; ++b)
+            for (int f = 0; f < F; ++f)
+                nf[b * F + f] = m->fields[f * m->n_local_nodes + nodes[b]];
+        for (int pt = 0; pt < N; ++pt)
+        {
+            if (side >= 0) // getSideNodeInds: nodes with the normal coordinate at the side's end
+            {
+                const int pi[3] = {pt % n, (pt / n) % n, pt / (n * n)};
+                const int axis  = (dim - 1) - side / 2;
+                if (pi[axis] != (side % 2 ? p : 0))
+                    continue;
+            }
+            KIn in;
+            prepareQp(rb, pt, m->elem_verts + el * nv * 3, nf.data(), F, kparams, time, qd, scratch, side, in);
+            std::fill(val.begin(), val.end(), 0.);
+            r->fun(in, val.data());
+            for (int e = 0; e < r->E; ++e)
+            {
+                const int64_t dof = static_cast< int64_t >(nodes[pt]) * dpn + dof_inds[e];
+                sum[dof] += val[e];
+                count[dof] += 1.;
+            }
+        }
     }
     return 0;
 }

@@ -45,7 +45,9 @@ enum
     ORC_RESIDUAL_LINEAR2D_ERROR    = 1, /* tests/Diffusion2D.hpp:84-92 (exact T = x), F = E = 3                     */
     ORC_RESIDUAL_LINEAR3D_ERROR    = 2, /* 3-D twin, F = E = 4                                                      */
     ORC_RESIDUAL_UNIT2D            = 3, /* tests/MappingTests.cpp:567-569: integrand 1, F = 0, E = 1                */
-    ORC_RESIDUAL_UNIT3D            = 4
+    ORC_RESIDUAL_UNIT3D            = 4,
+    ORC_RESIDUAL_COORDX2D          = 5, /* tests/Diffusion2D.hpp:49-50: out[0] = x (Dirichlet value kernel), F = 0  */
+    ORC_RESIDUAL_COORDX3D          = 6
 };
 
 /* dims of a kernel: returns 0 on success */
@@ -167,6 +169,12 @@ int orc_bnd_apply(const orc_mesh* m, int kernel_id, const double* kparams, doubl
 int orc_bnd_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, double time, int R, int64_t n_faces,
                      const int64_t* face_elem, const uint8_t* face_side, const double* dirichlet_vals, size_t ldg,
                      double* diag, double* rhs, size_t ldr);
+
+/* computeValuesAtNodes (algsys/ComputeValuesAtNodes.hpp:371-448,508-594): residual kernel evaluated at the nodes of the
+ * listed element sides (n_faces >= 0) or of all elements (n_faces < 0); sum[dof(node, dof_inds[e])] += value_e,
+ * count[...] += 1; the average sum/count (where count > 0) is the nodal value (:112-154) */
+int orc_values_at_nodes(const orc_mesh* m, int residual_id, const double* kparams, double time, int64_t n_faces,
+                        const int64_t* face_elem, const uint8_t* face_side, const int* dof_inds, double* sum, double* count);
 
 const char* orc_last_error(void);
 

@@ -269,6 +269,8 @@ RESIDUAL_LINEAR2D_ERROR = 1
 RESIDUAL_LINEAR3D_ERROR = 2
 RESIDUAL_UNIT2D = 3
 RESIDUAL_UNIT3D = 4
+RESIDUAL_COORDX2D = 5
+RESIDUAL_COORDX3D = 6
 
 _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
@@ -387,3 +389,19 @@ def bnd_diag_rhs(mesh, kid, face_elem, face_side, diag, rhs, dirichlet_vals=None
                                 fe.ctypes.data_as(_i64p), fs.ctypes.data_as(_u8p), _d(g), C.c_size_t(nl), _d(diag),
                                 _d(rhs), C.c_size_t(nl)))
     return diag, rhs
+
+
+def values_at_nodes(mesh, rid, dof_inds, face_elem=None, face_side=None, kparams=None, time=0.0):
+    """computeValuesAtNodes pieces: returns (sum, count) over local dofs; the nodal value is sum / count where count > 0."""
+    kpar = None if kparams is None else np.ascontiguousarray(kparams, dtype=np.float64)
+    di = np.ascontiguousarray(dof_inds, dtype=np.int32)
+    assert di.size == residual_params(rid)["E"]
+    s, c = np.zeros(mesh.n_local_dofs), np.zeros(mesh.n_local_dofs)
+    if face_elem is None:
+        nf, fe_p, fs_p = -1, None, None
+    else:
+        fe, fs = _faces(face_elem, face_side)
+        nf, fe_p, fs_p = len(fe), fe.ctypes.data_as(_i64p), fs.ctypes.data_as(_u8p)
+    _chk(lib().orc_values_at_nodes(C.byref(mesh.struct), rid, _d(kpar), C.c_double(time), C.c_int64(nf), fe_p, fs_p,
+                                   di.ctypes.data_as(_ip), _d(s), _d(c)))
+    return s, c

@@ -119,10 +119,13 @@ def test_k6_twin_linear_solution_with_adiabatic_walls(S, ctx):
     fe, fs = part.boundary_sides([0, 1, 2, 3])
     mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, fe, fs))
     coords = part.node_coords()
-    g = np.zeros((part.n_local_nodes, U))
-    g[:, 0] = coords[:, 0]
-    g = np.where(mask.reshape(-1, U) != 0, g, 0.0).reshape(1, -1)
-    diag, rhs = mf.diag_rhs(dev(g))
+    # setDirichletBCValues: the boundary residual kernel out[0] = x at the nodes of the Dirichlet sides, on the device
+    dfe, dfs = part.boundary_sides([4, 5])
+    g = S.values_at_nodes(mesh, S.RESIDUAL_COORDX3D, [0], torch.zeros(part.n_local_nodes * U, dtype=torch.float64, device="cuda"),
+                          face_elem=dfe, face_side=dfs)
+    want = np.where(mask.reshape(-1, U) != 0, np.stack([coords[:, 0]] + [np.zeros(len(coords))] * 3, axis=1), 0.0)
+    assert np.abs(g.cpu().numpy().reshape(-1, U) - want).max() < 1e-14
+    diag, rhs = mf.diag_rhs(g[None, :])
     x = torch.zeros_like(diag)
     res = solve.cg(lambda v, out: mf.apply(v[None, :], out[None, :]), rhs[0], x, solve.jacobi_inverse(diag), tol=1e-12,
                    residual_scaling="rhs", max_iters=5000)
@@ -222,3 +225,22 @@ def test_boundary_term_in_multi_rank_schedule(S, ctx, ne, parts):
         rows = np.array([row_of[int(g)] for g in gid])
         ref = y_ref.reshape(whole.n_local_nodes, U)[rows]
         assert np.linalg.norm(y.reshape(len(rows), U) - ref) < 1e-11 * np.linalg.norm(ref)
+
+
+def test_values_at_nodes_vs_oracle(S, ctx):
+    """computeValuesAtNodes on the device == the oracle: sums and visit counts of a field-reading kernel with
+    derivatives (Diffusion3D error kernel) on sides and on the whole mesh, distorted elements."""
+    p, U = 2, 4
+    part = S.CubePartition(3, p, perturb=0.15)
+    mesh = S.DeviceMesh(ctx, part, U)
+    rng = np.random.default_rng(3)
+    fields = rng.standard_normal((4, part.n_local_nodes))
+    om = helpers.oracle_mesh(part, p + 1, U, [0, 1, 2, 3], fields=fields)
+    fe, fs = part.boundary_sides([0, 3, 5])
+    for faces in ((fe, fs), (None, None)):
+        ws, wc = O.values_at_nodes(om, O.RESIDUAL_DIFFUSION3D_ERROR, [2, 0, 3, 1], faces[0], faces[1], kparams=[0.7, 1.3])
+        vals = torch.full((part.n_local_nodes * U,), 7.0, dtype=torch.float64, device="cuda")
+        S.values_at_nodes(mesh, S.RESIDUAL_DIFFUSION3D_ERROR, [2, 0, 3, 1], vals, fields=dev(fields), kernel_params=[0.7, 1.3],
+                          face_elem=faces[0], face_side=faces[1])
+        want = np.where(wc > 0, ws / np.maximum(wc, 1), 7.0)
+        assert helpers.rel_err(vals.cpu().numpy(), want) < 1e-12

@@ -157,3 +157,31 @@ def test_boundary_matrix_free_consistency():
     O.bnd_diag_rhs(mesh, O.KERNEL_ROBIN3D, [0] * 3, sides, diag, rhs, dirichlet_vals=g, kparams=kp)
     assert np.allclose(diag, np.diag(Ks), rtol=1e-12, atol=1e-13)
     assert np.allclose(rhs[:, 0], Fs[:, 0] - Ks @ g, rtol=1e-11, atol=1e-12)
+
+
+def test_values_at_nodes_dirichlet_kernel():
+    """setDirichletBCValues of K6 (tests/Diffusion2D.hpp:49-62): the boundary residual kernel out[0] = x evaluated at the
+    nodes of the left / right sides and averaged gives T = x there; nothing else is touched; nodes shared by two boundary
+    elements receive two contributions (algsys/ComputeValuesAtNodes.hpp:508-594,112-154)."""
+    en, ev, coords, faces = _square_mesh(4, 2)
+    U = 3
+    mesh = O.MeshView(2, 2, 3, en, ev, coords.shape[0], U, [0, 1, 2])
+    fe = [e for b in (3, 4) for e, _ in faces[b]]
+    fs = [s for b in (3, 4) for _, s in faces[b]]
+    s, c = O.values_at_nodes(mesh, O.RESIDUAL_COORDX2D, [0], fe, fs)
+    on = (coords[:, 0] == 0.0) | (coords[:, 0] == 1.0)
+    c2, s2 = c.reshape(-1, U), s.reshape(-1, U)
+    assert np.all(c2[~on] == 0) and np.all(c2[:, 1:] == 0)
+    assert set(np.unique(c2[on, 0])) == {1.0, 2.0}
+    assert np.allclose(s2[on, 0] / c2[on, 0], coords[on, 0], atol=1e-15)
+
+
+def test_values_at_nodes_normal_and_derivatives():
+    """A domain evaluation reproduces nodal fields and their gradients: the Linear2D error kernel on the exact fields
+    (T = x, dT/dx = 1, dT/dy = 0 as nodal fields) vanishes at every node; visit counts are 1, 2 or 4 per node."""
+    en, ev, coords, _ = _square_mesh(3, 3)
+    n = coords.shape[0]
+    fields = np.stack([coords[:, 0], np.ones(n), np.zeros(n)])
+    mesh = O.MeshView(2, 3, 4, en, ev, n, 3, [0, 1, 2], fields=fields)
+    s, c = O.values_at_nodes(mesh, O.RESIDUAL_LINEAR2D_ERROR, [0, 1, 2])
+    assert np.abs(s).max() < 1e-14 and set(np.unique(c)) == {1.0, 2.0, 4.0}
