@@ -773,7 +773,8 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     static const bool xcd_env   = std::getenv("L3K_FAST_NO_XCD") == nullptr;
     // measured (profiles/r01_kbench_xcd_mapping.log): order 6 gains 1 % and re-fetches less, order 4 loses 11 % (the
     // elements in flight on one XCD are neighbours: their atomics meet on the same lines)
-    const int         xcd_chunk = (P >= 6 && xcd_env && grid % 8 == 0 && n_batches >= int64_t(grid) && n_batches < (int64_t(1) << 30))
+    static const bool xcd_force = std::getenv("L3K_FAST_XCD") != nullptr;
+    const int         xcd_chunk = ((P >= 6 || xcd_force) && xcd_env && grid % 8 == 0 && n_batches >= int64_t(grid) && n_batches < (int64_t(1) << 30))
                                       ? int((n_batches + 7) / 8)
                                       : 0;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
