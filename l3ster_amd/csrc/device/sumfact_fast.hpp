@@ -617,7 +617,6 @@ __global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(cons
         if (act)
         {
             const double*   sb      = reinterpret_cast< const double* >(bufB);
-            const int64_t   el      = elemOf(batch);
             const bool flagged = flag_cur != 0;
             // measured (profiles/r01_kbench_scatter_variants.log): two unknowns per lane and round halve the loop overhead
             // and give 16-byte stores on exclusive nodes, but halve the density of the atomic wave-instructions; it wins
