@@ -162,6 +162,9 @@ int l3k_unpack_add_rows(l3k_ctx* ctx, const double* d_src, int64_t n, const int3
  * the caller zeroes them first (:921-923).  finalize != 0 sets diag = 1, rhs = g on owned Dirichlet rows (:911-915). */
 int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
                     size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg, int finalize);
+/* the finalisation alone (diag = 1, rhs = g on owned Dirichlet rows, :911-915): partitioned systems call l3k_mf_diag_rhs
+ * with finalize = 0, export-add the ghost rows to their owners (:925-938), then this */
+int l3k_mf_dirichlet_finalize(l3k_mf* mf, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs, size_t ldr);
 
 /* ---- boundary equation kernels on element sides ---------------------------------------------------------------------
  * assembleProblem(kernel, boundary_ids) with a BoundaryEquationKernel (algsys/MatrixFreeSystem.hpp:58-68): the term

@@ -1101,6 +1101,22 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
     return 0;
 }
 
+int l3k_mf_dirichlet_finalize(l3k_mf* mf, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs, size_t ldr)
+{
+    if (!mf || !d_diag || !d_rhs)
+    {
+        setError("l3k_mf_dirichlet_finalize: null argument");
+        return -1;
+    }
+    const auto& rows = mf->mesh->owned_dirichlet_rows;
+    if (rows.n == 0)
+        return 0;
+    hipLaunchKernelGGL(dirichletFinalizeKernel, dim3(gridFor(int64_t(rows.n))), dim3(256), 0, mf->ctx->stream, rows.ptr,
+                       int64_t(rows.n), d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, mf->n_rhs);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+
 int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum)
 {
     if (!mf)

@@ -111,3 +111,59 @@ class DistributedOperator:
             be.unpack_add_rows(rbuf, idx, Y)
         be.dirichlet_rows(X, Y, alpha)
         return Y
+
+    def import_ghosts(self, V):
+        """comm::Import of a multivector over the owned rows: returns the (ncols, n_ghost_dofs) ghost rows (owner ->
+        sharer copy, comm/ImportExport.hpp:295-372)."""
+        be, plan = self.backend, self.plan
+        nc = V.shape[0]
+        ghost = torch.zeros((nc, max(plan.n_ghost_dofs, 1)), dtype=torch.float64, device=V.device)
+        sends, recvs, stages = [], [], []
+        for nb, idx in plan.sharers:
+            sbuf = torch.empty((nc, idx.numel()), dtype=torch.float64, device=V.device)
+            be.pack_rows(V, idx, sbuf)
+            sends.append((nb, sbuf))
+        for nb, g0, g1 in plan.owners:
+            stage = torch.empty((nc, g1 - g0), dtype=torch.float64, device=V.device)
+            stages.append((g0, g1, stage))
+            recvs.append((nb, stage))
+        self.transport.wait(self.transport.post(sends, recvs))
+        for g0, g1, stage in stages:
+            ghost[:, g0:g1].copy_(stage)
+        return ghost
+
+    def export_add(self, ghost, owned):
+        """comm::Export: adds every ghost row into its owner's row (sharer -> owner, comm/ImportExport.hpp:402-470)."""
+        be, plan = self.backend, self.plan
+        nc = owned.shape[0]
+        sends, recvs = [], []
+        for nb, g0, g1 in plan.owners:
+            sends.append((nb, ghost[:, g0:g1].contiguous()))
+        for nb, idx in plan.sharers:
+            recvs.append((nb, torch.empty((nc, idx.numel()), dtype=torch.float64, device=owned.device)))
+        self.transport.wait(self.transport.post(sends, recvs))
+        for (nb, idx), (_, rbuf) in zip(plan.sharers, recvs):
+            be.unpack_add_rows(rbuf, idx, owned)
+
+    def diag_rhs(self, dirichlet_vals_owned=None):
+        """computeDiagAndRhs of a partitioned system (algsys/MatrixFreeSystem.hpp:888-941): Dirichlet values imported to
+        the ghost rows, local diag / rhs of interior and border elements, ghost rows exported and added to their
+        owners, Dirichlet rows finalised.  dirichlet_vals_owned: (n_rhs, n_owned_dofs) or None.
+        Returns (diag [n_owned], rhs (n_rhs, n_owned))."""
+        be = self.backend
+        n_owned, n_ghost = be.mesh.n_owned_dofs, be.mesh.n_ghost_dofs
+        g_all = None
+        if dirichlet_vals_owned is not None:
+            g_all = torch.cat([dirichlet_vals_owned, self.import_ghosts(dirichlet_vals_owned)[:, :n_ghost]], dim=1).contiguous()
+        dev = "cuda"
+        diag = torch.zeros(n_owned, dtype=torch.float64, device=dev)
+        rhs = torch.zeros((be.n_rhs, n_owned), dtype=torch.float64, device=dev)
+        dg = torch.zeros(max(n_ghost, 1), dtype=torch.float64, device=dev)
+        rg = torch.zeros((be.n_rhs, max(n_ghost, 1)), dtype=torch.float64, device=dev)
+        be.diag_rhs(g_all, which=2, diag=diag, rhs=rhs, diag_ghost=dg, rhs_ghost=rg, finalize=False)
+        both_g = torch.cat([dg[None, :], rg], dim=0).contiguous()   # one exchange for diag and rhs
+        both_o = torch.cat([diag[None, :], rhs], dim=0).contiguous()
+        self.export_add(both_g, both_o)
+        diag, rhs = both_o[0].contiguous(), both_o[1:].contiguous()
+        be.dirichlet_finalize(dirichlet_vals_owned, diag, rhs)
+        return diag, rhs

@@ -95,7 +95,7 @@ def pcg(system, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="n
 
 
 def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="none", group=None,
-                    throw_on_fail=True):
+                    throw_on_fail=True, allreduce=None):
     """The same iteration for a partitioned system: `op.apply(X, Y)` is a DistributedOperator over this rank's owned
     rows; the fused l3k_cg_* kernels keep the scalars in a device block that is all-reduced between them (two small
     all-reduces per iteration, as Belos does)."""
@@ -109,7 +109,9 @@ def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residu
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
     def reduce(view):
-        if multi:
+        if allreduce is not None:  # pluggable (the threaded multi-rank emulation of the tests)
+            allreduce(view)
+        elif multi:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
 
     op.apply(x[None, :], r[None, :])

@@ -487,6 +487,12 @@ class MatrixFreeSystem:
                                           _ptr(diag_ghost), _ptr(rhs_ghost), max(n_ghost, 1), int(finalize)))
         return diag, rhs
 
+    def dirichlet_finalize(self, dirichlet_vals, diag, rhs):
+        """diag = 1, rhs = g on the owned Dirichlet rows (the last step of computeDiagAndRhs, after the export)"""
+        g = dirichlet_vals
+        check(capi.load().l3k_mf_dirichlet_finalize(self._h, _ptr(g), 0 if g is None else g.shape[1], _ptr(diag), _ptr(rhs),
+                                                    rhs.shape[1]))
+
     def local_assemble(self, first=0, count=None, want_K=True, want_F=True, want_checksum=False):
         """assembleLocalSystem for elements [first, first+count) (algsys/AssembleLocalSystem.hpp:234-256).
         Returns (K [count, Nd, Nd] row-major, F [count, n_rhs, Nd] i.e. column-major Nd x n_rhs per element, checksum)."""

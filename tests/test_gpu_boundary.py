@@ -244,3 +244,93 @@ def test_values_at_nodes_vs_oracle(S, ctx):
                           face_elem=faces[0], face_side=faces[1])
         want = np.where(wc > 0, ws / np.maximum(wc, 1), 7.0)
         assert helpers.rel_err(vals.cpu().numpy(), want) < 1e-12
+
+
+class ThreadAllReduce:
+    """Sum all-reduce between the rank-threads of the single-GPU multi-rank emulation."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+
+    def bind(self, rank):
+        def allreduce(view):
+            torch.cuda.synchronize()
+            self.slots[rank] = view.clone()
+            self.barrier.wait(timeout=120)
+            total = sum(self.slots[r] for r in range(self.world))
+            self.barrier.wait(timeout=120)
+            view.copy_(total)
+            torch.cuda.synchronize()
+        return allreduce
+
+
+@pytest.mark.parametrize("ne,parts", [((4, 4, 2), (2, 2, 1)), ((4, 4, 4), (2, 2, 2))])
+def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
+    """The whole partitioned flow on emulated ranks: Dirichlet values from a boundary residual kernel (contributions
+    exported to the owners and averaged), diag / rhs with import of the Dirichlet values and export of the ghost rows,
+    boundary term, native PCG pieces with all-reduced scalars -- reproduces T = x, q = (1, 0, 0) on a distorted mesh."""
+    import queue
+    import threading
+    from l3ster_amd import solve
+    from l3ster_amd.distributed import DistributedOperator, HaloPlan
+    from test_gpu_apply import ThreadTransport
+    p, U = 2, 4
+    world = int(np.prod(parts))
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    red = ThreadAllReduce(world)
+    out, errors = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            part = S.CubePartition(ne, p, parts, rank, perturb=0.1)
+            mask = part.dirichlet_mask(U, sides=(4, 5))
+            c = S.Context(0, torch.cuda.current_stream().cuda_stream)
+            mesh = S.DeviceMesh(c, part, U, mask)
+            mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 0.0])
+            mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, *part.boundary_sides([0, 1, 2, 3])))
+            op = DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes))
+            n_owned = part.n_owned_nodes * U
+            # setDirichletBCValues on a partition: local sums / counts, ghost rows to their owners, average
+            import ctypes as C
+            from l3ster_amd import capi
+            lib = capi.load()
+            nl = part.n_local_nodes * U
+            sc = torch.zeros((2, nl), dtype=torch.float64, device="cuda")
+            fe, fs = part.boundary_sides([4, 5])
+            di = (C.c_int * 1)(0)
+            capi.check(lib.l3k_values_at_nodes(c._h, mesh._h, S.RESIDUAL_COORDX3D, None, 0, None, 0, 0.0, fe.size,
+                                               fe.ctypes.data_as(capi.c_int64_p), fs.ctypes.data_as(capi.c_uint8_p), di,
+                                               C.c_void_p(sc[0].data_ptr()), C.c_void_p(sc[1].data_ptr())))
+            owned = sc[:, :n_owned].contiguous()
+            op.export_add(sc[:, n_owned:].contiguous() if nl > n_owned else torch.zeros((2, 1), dtype=torch.float64, device="cuda"), owned)
+            g = torch.zeros(n_owned, dtype=torch.float64, device="cuda")
+            capi.check(lib.l3k_average_values(c._h, C.c_void_p(owned[0].data_ptr()), C.c_void_p(owned[1].data_ptr()), n_owned,
+                                              C.c_void_p(g.data_ptr())))
+            diag, rhs = op.diag_rhs(g[None, :])
+            x = torch.zeros(n_owned, dtype=torch.float64, device="cuda")
+            res = solve.pcg_distributed(op, c, rhs[0], x, solve.jacobi_inverse_native(c, diag), tol=1e-12,
+                                        residual_scaling="rhs", max_iters=5000, allreduce=red.bind(rank))
+            torch.cuda.synchronize()
+            coords = part.node_coords()[:part.n_owned_nodes]
+            sol = x.view(-1, U).cpu().numpy()
+            out[rank] = (res.num_iters, np.abs(sol[:, 0] - coords[:, 0]).max(), np.abs(sol[:, 1] - 1.0).max(),
+                         np.abs(sol[:, 2:]).max())
+        except Exception as exc:  # pragma: no cover
+            errors.append((rank, repr(exc)))
+            try:
+                red.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    iters = {v[0] for v in out.values()}
+    assert len(iters) == 1  # every rank saw the same reduced scalars
+    for r in range(world):
+        assert out[r][1] < 1e-9 and out[r][2] < 1e-8 and out[r][3] < 1e-8, (r, out[r])
