@@ -984,11 +984,31 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     a.alpha     = alpha;
     a.beta      = beta;
     a.fuse_beta = mf->fuse;
-    const auto* inst = instanceFor(mf, ncols);
-    if (!inst)
-        return -4;
-    if (int rc = inst->apply(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream))
-        return rc;
+    const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
+    const auto* inst = l3k::dev::findInstance(mf->kernel_id, mf->mesh->order, mf->nq, ncols);
+    if (inst)
+    {
+        if (int rc = inst->apply(a, blob, mf->ctx->stream))
+            return rc;
+    }
+    else
+    {
+        // no ncols-column instantiation: column by column with the single-column one, as the reference does when
+        // fewer columns than n_rhs are passed (algsys/MatrixFreeSystem.hpp:1124-1138)
+        inst = instanceFor(mf, 1);
+        if (!inst)
+            return -4;
+        for (int c = 0; c < ncols; ++c)
+        {
+            l3k::dev::ElemArgs ac = a;
+            ac.x  = d_x + ldx * c;
+            ac.xg = d_xghost ? d_xghost + ldxg * c : nullptr;
+            ac.y  = d_y + ldy * c;
+            ac.yg = d_yghost ? d_yghost + ldyg * c : nullptr;
+            if (int rc = inst->apply(ac, blob, mf->ctx->stream))
+                return rc;
+        }
+    }
     // boundary equation kernels registered on this system act on the sides of the same element range
     for (l3k_bnd* b : mf->boundary_terms)
         if (int rc = bndApplyImpl(b, which, d_x, ldx, d_xghost, ldxg, d_y, ldy, d_yghost, ldyg, ncols, alpha))

@@ -79,6 +79,8 @@ MESH_CASES = [
     (system.KERNEL_DIFFUSION3D_VAR, 3, 4, 1, 1, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1, 0.1),
+    # 3 columns without a 3-column instantiation of this shape: column by column (MatrixFreeSystem.hpp:1124-1138)
+    (system.KERNEL_DIFFUSION3D, 3, 4, 1, 3, 0.1),
 ]
 
 
