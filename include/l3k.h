@@ -83,6 +83,12 @@ enum
     L3K_RESIDUAL_COORDX3D          = 6  /* 3-D twin of tests/Diffusion2D.hpp:49-50: out[0] = x (Dirichlet value kernel) */
 };
 int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_t* param_bytes);
+/* Kernels that are not compiled into libl3k.so: a kernel PLUGIN is a shared library built from the user's functor (the
+ * reference compiles the user's lambda with the application; here `l3ster_amd.plugin.compile_kernel` / the Makefile
+ * fragment in INTEGRATION.md run hipcc on a generated translation unit that instantiates the element kernels for the
+ * functor and the requested (order, nq, ncols) shapes).  Loading it registers the kernel id and its instantiations;
+ * ids >= 1000 are free for plugins. */
+int l3k_plugin_load(const char* path);
 /* number of (kernel, order, nq, ncols) device instantiations, and the i-th one: for "is this shape built?" queries */
 int l3k_instance_count(void);
 int l3k_instance_info(int i, int* kernel_id, int* order, int* nq, int* ncols);

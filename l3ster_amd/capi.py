@@ -60,6 +60,7 @@ SIGNATURES = {
     "l3k_basis_1d": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p]),
     "l3k_colloc_deriv": (C.c_int, [C.c_int, c_double_p]),
     "l3k_kernel_info": (C.c_int, [C.c_int, C.POINTER(KParams), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
+    "l3k_plugin_load": (C.c_int, [C.c_char_p]),
     "l3k_instance_count": (C.c_int, []),
     "l3k_instance_info": (C.c_int, [C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
     "l3k_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
@@ -124,6 +125,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise L3KError(f"{LIB_PATH} is missing: build the HIP extension first (python -m l3ster_amd.build). "
                        "There is no CPU fallback for the device path.")
+    # torch ships its own HIP runtime (same soname as /opt/rocm's, which libl3k.so names in its RUNPATH): whichever is
+    # mapped first serves the whole process, and device memory / streams come from torch here -- so torch goes first
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure C-ABI use without torch: the system runtime
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -387,19 +389,40 @@ const std::vector< KernelMeta >& residualMetas()
     }();
     return metas;
 }
+// kernels announced by plugins (l3k_plugin_load): metadata materialised on first sight
+const KernelMeta* fromPlugin(int id, bool residual)
+{
+    struct Seen
+    {
+        KernelMeta meta;
+        bool       residual;
+    };
+    static std::vector< std::unique_ptr< Seen > > seen;
+    for (const auto& k : seen)
+        if (k->meta.id == id && k->residual == residual)
+            return &k->meta;
+    const auto* pk = l3k::dev::findPluginKernel(id, residual);
+    if (!pk)
+        return nullptr;
+    seen.push_back(std::make_unique< Seen >(Seen{KernelMeta{pk->id,
+                                                            {pk->dimension, pk->n_equations, pk->n_unknowns, pk->n_fields, pk->n_rhs},
+                                                            pk->name, pk->param_bytes, pk->kind == 1},
+                                                 residual}));
+    return &seen.back()->meta;
+}
 const KernelMeta* findResidual(int id)
 {
     for (const auto& k : residualMetas())
         if (k.id == id)
             return &k;
-    return nullptr;
+    return fromPlugin(id, true);
 }
 const KernelMeta* findKernel(int id)
 {
     for (const auto& k : kernelMetas())
         if (k.id == id)
             return &k;
-    return nullptr;
+    return fromPlugin(id, false);
 }
 
 int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
@@ -653,6 +676,22 @@ int l3k_kernel_info(int kernel_id, l3k_kparams* params, const char** name, size_
         *name = k->name;
     if (param_bytes)
         *param_bytes = k->bytes;
+    return 0;
+}
+int l3k_plugin_load(const char* path)
+{
+    if (!path)
+    {
+        setError("l3k_plugin_load: null path");
+        return -1;
+    }
+    // the plugin's static registrars call registerPluginKernel / registerInstance / ... of THIS library
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+    {
+        setError("l3k_plugin_load: %s", dlerror());
+        return -1;
+    }
     return 0;
 }
 int l3k_instance_count(void)

@@ -126,6 +126,18 @@ const BoundaryInstance* findBoundaryInstance(int kernel_id, int order, int nq, i
 void                    registerIntegralInstance(const IntegralInstance& inst);
 const IntegralInstance* findIntegralInstance(int residual_id, int order, int nq);
 
+// Kernel metadata of functors that are not compiled into libl3k.so: kernel plugins (shared libraries built from a
+// user's functor by l3ster_amd/plugin.py, loaded with l3k_plugin_load) announce themselves here from static registrars.
+struct PluginKernel
+{
+    int         id, kind; // kind 0 domain equation kernel, 1 boundary equation kernel, 2 residual kernel
+    int         dimension, n_equations, n_unknowns, n_fields, n_rhs;
+    const char* name;
+    size_t      param_bytes;
+};
+void                registerPluginKernel(const PluginKernel& k);
+const PluginKernel* findPluginKernel(int id, bool residual);
+
 void            registerInstance(const Instance& inst);
 const Instance* findInstance(int kernel_id, int order, int nq, int ncols);
 int             instanceCount();

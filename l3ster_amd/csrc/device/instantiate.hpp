@@ -3,6 +3,8 @@
 #ifndef L3K_DEVICE_INSTANTIATE_HPP
 #define L3K_DEVICE_INSTANTIATE_HPP
 
+#include <type_traits>
+
 #include "../user_kernels.hpp"
 #include "sumfact_apply.hpp"
 #include "sumfact_fast.hpp"
@@ -61,6 +63,20 @@ constexpr LaunchFn selectApply()
                                           ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >()});             \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
+    }
+// A kernel plugin announces its functor: id, kind (0 domain, 1 boundary, 2 residual), name
+#define L3K_PLUGIN_KERNEL(ID, KIND, T, NAME)                                                                           \
+    namespace                                                                                                          \
+    {                                                                                                                  \
+    const struct L3K_CAT(PRegistrar_, __LINE__)                                                                        \
+    {                                                                                                                  \
+        L3K_CAT(PRegistrar_, __LINE__)()                                                                               \
+        {                                                                                                              \
+            ::l3k::dev::registerPluginKernel({ID, KIND, T::params.dimension, T::params.n_equations, T::params.n_unknowns, \
+                                              T::params.n_fields, T::params.n_rhs, NAME,                              \
+                                              std::is_empty_v< T > ? size_t{0} : sizeof(T)});                         \
+        }                                                                                                              \
+    } L3K_CAT(pregistrar_, __LINE__);                                                                                  \
     }
 #define L3K_INSTANTIATE_BOUNDARY(T, P, NQ, R)                                                                          \
     namespace                                                                                                          \

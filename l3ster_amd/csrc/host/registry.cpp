@@ -28,6 +28,26 @@ std::vector< IntegralInstance >& integralTable()
 }
 } // namespace
 
+namespace
+{
+std::vector< PluginKernel >& pluginKernels()
+{
+    static std::vector< PluginKernel > t;
+    return t;
+}
+} // namespace
+void registerPluginKernel(const PluginKernel& k)
+{
+    pluginKernels().push_back(k);
+}
+const PluginKernel* findPluginKernel(int id, bool residual)
+{
+    for (const auto& k : pluginKernels())
+        if (k.id == id && (k.kind == 2) == residual)
+            return &k;
+    return nullptr;
+}
+
 void registerBoundaryInstance(const BoundaryInstance& inst)
 {
     boundaryTable().push_back(inst);
