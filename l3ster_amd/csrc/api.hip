@@ -816,7 +816,7 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
             if (count[d->elem_nodes[i]] < 2)
                 ++count[d->elem_nodes[i]];
         int64_t b = d->n_owned_nodes;
-        while (b > 0 && count[b - 1] <= 1)
+        while (b > 0 && count[b - 1] == 1) // exactly one: a node no element touches still needs the beta scaling
             --b;
         m->exclusive_begin = b;
         m->exclusive_end   = d->n_owned_nodes;

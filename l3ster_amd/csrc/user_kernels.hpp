@@ -243,6 +243,8 @@ struct Unit3D
     X(::l3k::kernels::Diffusion3D, 4, 5, 1)                                                                            \
     X(::l3k::kernels::Diffusion3D, 5, 6, 1)                                                                            \
     X(::l3k::kernels::Diffusion3D, 6, 7, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 7, 8, 1)                                                                            \
+    X(::l3k::kernels::Diffusion3D, 8, 9, 1)                                                                            \
     X(::l3k::kernels::Diffusion3D, 3, 7, 1)                                                                            \
     X(::l3k::kernels::Diffusion3D, 3, 7, 3)                                                                            \
     X(::l3k::kernels::Diffusion3D, 2, 3, 2)                                                                            \

@@ -79,6 +79,9 @@ MESH_CASES = [
     (system.KERNEL_DIFFUSION3D_VAR, 3, 4, 1, 1, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1, 0.1),
+    # orders above 6: the one-wave-per-element kernel does not fit (81 pencils > 64 lanes), the generic LDS kernel runs
+    (system.KERNEL_DIFFUSION3D, 2, 7, 1, 1, 0.1),
+    (system.KERNEL_DIFFUSION3D, 2, 8, 1, 1, 0.1),
     # 3 columns without a 3-column instantiation of this shape: column by column (MatrixFreeSystem.hpp:1124-1138)
     (system.KERNEL_DIFFUSION3D, 3, 4, 1, 3, 0.1),
 ]
@@ -166,6 +169,7 @@ DIAG_CASES = [
     (system.KERNEL_DIFFUSION3D, 3, 2, 1, 1),
     (system.KERNEL_DIFFUSION3D, 2, 3, 2, 3),
     (system.KERNEL_DIFFUSION3D, 2, 6, 1, 1),
+    (system.KERNEL_DIFFUSION3D, 2, 8, 1, 1),
     (system.KERNEL_DIFFUSION3D_VAR, 2, 3, 2, 2),
     (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1),
     (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2),

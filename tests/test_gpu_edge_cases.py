@@ -1,0 +1,88 @@
+"""Empty and degenerate inputs through the C ABI on the GPU (the reference's tests exercise empty domains / boundary
+views and zero-sized ranges implicitly through its views; here they are explicit)."""
+import numpy as np
+import pytest
+
+import helpers
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from l3ster_amd import system
+    return system
+
+
+@pytest.fixture(scope="module")
+def ctx(S):
+    torch.cuda.set_device(0)
+    return S.Context(0, torch.cuda.current_stream().cuda_stream)
+
+
+class EmptyMesh:
+    """A partition that owns nodes but no elements (possible for a rank of a badly balanced partition)."""
+    dim, order = 3, 2
+    n_elems = n_interior_elems = 0
+    n_owned_nodes, n_ghost_nodes = 5, 0
+    elem_nodes = np.zeros((0, 27), np.uint32)
+    elem_verts = np.zeros((0, 8, 3))
+    n_local_nodes = 5
+
+
+def test_mesh_without_elements(S, ctx):
+    U = 4
+    mask = np.zeros(5 * U, np.uint8)
+    mask[[0, 7]] = 1
+    mesh = S.DeviceMesh(ctx, EmptyMesh(), U, mask)
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    x = torch.arange(1.0, 21.0, dtype=torch.float64, device="cuda")[None, :]
+    y = torch.full_like(x, 3.0)
+    mf.apply(x, y, 2.0, 0.5)  # y <- 0.5*y + 2*x on Dirichlet rows (MatrixFreeSystem.hpp:1038,1087-1098)
+    want = np.full(20, 1.5)
+    want[[0, 7]] += 2.0 * np.array([1.0, 8.0])
+    assert np.array_equal(y.cpu().numpy()[0], want)
+    diag, rhs = mf.diag_rhs(None)
+    assert diag.cpu().numpy()[[0, 7]].tolist() == [1.0, 1.0] and diag.sum().item() == 2.0 and rhs.abs().sum().item() == 0.0
+    K, F, cs = mf.local_assemble(0, 0, want_checksum=True)
+    assert K.shape[0] == 0 and cs.numel() == 0
+    assert S.integrate(mesh, S.RESIDUAL_UNIT3D).tolist() == [0.0]
+
+
+def test_empty_side_lists(S, ctx):
+    part = S.CubePartition(2, 2)
+    U = 4
+    mesh = S.DeviceMesh(ctx, part, U)
+    none = (np.zeros(0, np.int64), np.zeros(0, np.uint8))
+    term = S.BoundaryTerm(mesh, S.KERNEL_ROBIN3D, *none, kernel_params=[1.0, 1.0])
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    x = torch.as_tensor(part.synthetic_vector(U), device="cuda")
+    y_plain = torch.zeros_like(x)
+    mf.apply(x, y_plain)
+    mf.attach_boundary(term)
+    y_bnd = torch.zeros_like(x)
+    mf.apply(x, y_bnd)
+    assert helpers.rel_err(y_bnd.cpu().numpy(), y_plain.cpu().numpy()) < 1e-13  # an empty boundary adds nothing
+    assert S.integrate(mesh, S.RESIDUAL_UNIT3D, asm_opts=(1, 0, 0), face_elem=none[0], face_side=none[1]).tolist() == [0.0]
+    vals = torch.full((part.n_local_nodes * U,), 2.5, dtype=torch.float64, device="cuda")
+    S.values_at_nodes(mesh, S.RESIDUAL_COORDX3D, [0], vals, face_elem=none[0], face_side=none[1])
+    assert torch.all(vals == 2.5)
+
+
+def test_argument_errors_are_reported(S, ctx):
+    part = S.CubePartition(2, 2)
+    mesh = S.DeviceMesh(ctx, part, 4)
+    with pytest.raises(S.L3KError, match="outside the mesh"):
+        S.BoundaryTerm(mesh, S.KERNEL_ROBIN3D, [99], [0], kernel_params=[1.0, 1.0])
+    with pytest.raises(S.L3KError, match="outside the mesh"):
+        S.integrate(mesh, S.RESIDUAL_UNIT3D, face_elem=[0], face_side=[6])
+    with pytest.raises(S.L3KError, match="boundary equation kernel"):
+        S.MatrixFreeSystem(mesh, S.KERNEL_ROBIN3D, [1.0, 1.0])
+    with pytest.raises(S.L3KError, match="not a boundary"):
+        S.BoundaryTerm(mesh, S.KERNEL_DIFFUSION3D, [0], [0], kernel_params=[1.0, 1.0])
+    with pytest.raises(S.L3KError, match="no device instantiation"):
+        S.integrate(mesh, S.RESIDUAL_DIFFUSION3D_ERROR, torch.zeros((4, part.n_local_nodes), dtype=torch.float64, device="cuda"),
+                    asm_opts=(3, 0, 0))
+    with pytest.raises(S.L3KError, match="16-byte|parameter block"):
+        S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0])
