@@ -92,6 +92,23 @@ def test_single_part_mesh_conventions(ne, p):
 def test_partition_ownership_and_exchange_plan(ne, p, parts):
     """util/SegmentedOwnership.hpp:11-45 (contiguous owned ranges, shared sorted by global id),
     comm/ImportExport.hpp:29-72 (who shares my owned indices / who owns my shared ones)."""
+    check_partition(ne, p, parts)
+
+
+def test_partition_invariants_random_shapes():
+    """The same invariants on randomly drawn meshes, uneven block splits included (hypothesis)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None)
+    @given(st.tuples(st.integers(1, 5), st.integers(1, 5), st.integers(1, 4)), st.integers(1, 3), st.data())
+    def run(ne, p, data):
+        parts = tuple(data.draw(st.integers(1, min(n, 3))) for n in ne)
+        check_partition(ne, p, parts)
+
+    run()
+
+
+def check_partition(ne, p, parts):
     nparts = int(np.prod(parts))
     pm = [system.CubePartition(ne, p, parts, r) for r in range(nparts)]
     whole = system.CubePartition(ne, p)

@@ -86,3 +86,31 @@ def test_argument_errors_are_reported(S, ctx):
                     asm_opts=(3, 0, 0))
     with pytest.raises(S.L3KError, match="16-byte|parameter block"):
         S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_apply_and_diag_rhs_parity(S, ctx, seed):
+    """Seeded random problems: element counts, order, distortion, Dirichlet dofs anywhere (any unknown, interior nodes
+    included), alpha / beta, columns -- apply, diagonal and lifted rhs against the oracle."""
+    import oracle_lib as O
+    rng = np.random.default_rng(1000 + seed)
+    p = int(rng.integers(1, 7))
+    ne = tuple(int(v) for v in rng.integers(1, 4 if p > 3 else 5, size=3))
+    U = 4
+    part = S.CubePartition(ne, p, perturb=float(rng.uniform(0, 0.15)))
+    mask = (rng.uniform(size=part.n_local_nodes * U) < rng.choice([0.0, 0.02, 0.2])).astype(np.uint8)
+    mesh = S.DeviceMesh(ctx, part, U, mask if mask.any() or seed % 2 else None)
+    kp = [float(rng.uniform(0.5, 2)), float(rng.uniform(-1, 1))]
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, kp)
+    om = helpers.oracle_mesh(part, p + 1, U, np.arange(U), mask if mask.any() or seed % 2 else None)
+    alpha, beta = float(rng.uniform(-2, 2)), float(rng.choice([0.0, 1.0, rng.uniform(-1, 1)]))
+    x = rng.standard_normal((1, part.n_local_nodes * U))
+    y0 = rng.standard_normal(x.shape)
+    Y = torch.as_tensor(y0, device="cuda").clone()
+    mf.apply(torch.as_tensor(x, device="cuda"), Y, alpha, beta)
+    want = O.mf_apply(om, O.KERNEL_DIFFUSION3D, x.T, np.asfortranarray(y0.T.copy()), alpha=alpha, beta=beta, kparams=kp)
+    assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-11, (p, ne)
+    g = np.where(mask != 0, rng.standard_normal(mask.size), 0.0)[None, :]
+    diag, rhs = mf.diag_rhs(torch.as_tensor(g, device="cuda"))
+    wd, wr = O.mf_diag_rhs(om, O.KERNEL_DIFFUSION3D, dirichlet_vals=np.asfortranarray(g.T), kparams=kp)
+    assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-11 and helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-10, (p, ne)
