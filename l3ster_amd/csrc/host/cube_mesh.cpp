@@ -11,7 +11,7 @@
 // (comm/ImportExport.hpp:29-72).
 //
 // Locality choices (free in the reference, which takes whatever the mesh file / METIS gives): elements are traversed in
-// 4x4x4 bricks; every owned non-internal node is numbered with its "home" element (the element that has it on a
+// bricks (edge chosen by brickEdge below); every owned non-internal node is numbered with its "home" element (the element that has it on a
 // high face), faces first so that each face's (p-1)^2 nodes are one contiguous run, then edges, then vertices.
 #include "l3k.h"
 
@@ -19,6 +19,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <memory>
 #include <unordered_map>
@@ -32,7 +33,19 @@ void setError(const char* fmt, ...);
 namespace
 {
 using i64 = int64_t;
-constexpr int brick = 4;
+// Elements are traversed in brick x brick x brick blocks.  The brick edge is a free choice of this implementation (the
+// reference takes whatever order the mesh generator / METIS gives); measured on MI355X (profiles/r01_kbench_brick_sweep.log,
+// 64^3 elements): power-of-two edges alias -- the node rows that the ~1800 resident waves touch at the same time are then
+// a power-of-two apart in HBM -- and cost 5 % at order 6 (edge 4: 15.9 ns per element, 6: 15.1) and 27 % at order 4
+// (edge 4: 6.9, 12: 5.0).  Default: 6 for orders >= 5, 12 below (more elements per wave there); L3K_MESH_BRICK overrides.
+int brickEdge(int order)
+{
+    static const int env = [] {
+        const char* e = std::getenv("L3K_MESH_BRICK");
+        return e ? std::atoi(e) : 0;
+    }();
+    return env > 0 ? env : (order >= 5 ? 6 : 12);
+}
 
 struct TypeTable // homed non-internal nodes of an element whose low-boundary flags are (fx, fy, fz)
 {
@@ -141,6 +154,7 @@ struct PartNumbering
         n_elems = i64(ext[0]) * ext[1] * ext[2];
         trav_pos.assign(n_elems, -1);
         trav_elem.reserve(n_elems);
+        const int brick = brickEdge(L.p);
         for (int bz = 0; bz < ext[2]; bz += brick)
             for (int by = 0; by < ext[1]; by += brick)
                 for (int bx = 0; bx < ext[0]; bx += brick)
