@@ -1,42 +1,11 @@
 // api.hip -- the extern "C" surface of libl3k.so (include/l3k.h) plus the small vector kernels around the element
 // kernels (scale, Dirichlet rows, pack / unpack-add).  No CPU fallback: without a usable HIP device every device entry
 // point fails with an error.
-#include "l3k.h"
+#include "objects.hpp"
 
-#include "device/common.hpp"
-#include "host/tables.hpp"
-#include "user_kernels.hpp"
-
-#include <hip/hip_runtime.h>
-
-#include <dlfcn.h>
-
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <type_traits>
-#include <string>
-#include <utility>
-#include <vector>
-
-namespace l3k::dev
-{
-const char* lastError();
-}
-using l3k::dev::setError;
-
-#define L3K_HIP(call)                                                                                                  \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        const hipError_t err_ = (call);                                                                                \
-        if (err_ != hipSuccess)                                                                                        \
-        {                                                                                                              \
-            setError("%s failed: %s (%s:%d)", #call, hipGetErrorString(err_), __FILE__, __LINE__);                     \
-            return -3;                                                                                                 \
-        }                                                                                                              \
-    } while (0)
+using l3k::api::KernelMeta;
+using l3k::api::findKernel;
+using l3k::api::findResidual;
 
 // ------------------------------------------------------------------------------------------------ small kernels
 namespace
@@ -100,264 +69,10 @@ __global__ void unpackAddKernel(const double* __restrict__ src, int64_t n, const
             dst[r + ld * c] += src[i + n * c];
     }
 }
-constexpr int reduce_threads = 256;
-// out[v] = sum_b partial[b][v], fixed summation order (one workgroup per component)
-__global__ __launch_bounds__(reduce_threads) void reducePartialsKernel(const double* __restrict__ partial, int64_t n_blocks,
-                                                                         int nv, double* __restrict__ out)
-{
-    __shared__ double scratch[reduce_threads];
-    const int         tid = threadIdx.x, v = blockIdx.x;
-    double            s   = 0.;
-    for (int64_t b = tid; b < n_blocks; b += reduce_threads)
-        s += partial[b * nv + v];
-    scratch[tid] = s;
-    __syncthreads();
-    for (int w = reduce_threads / 2; w > 0; w >>= 1)
-    {
-        if (tid < w)
-            scratch[tid] += scratch[tid + w];
-        __syncthreads();
-    }
-    if (tid == 0)
-        out[v] = scratch[0];
-}
-
-
-// ---- fused vector kernels of the Jacobi-PCG iteration (solve/BelosSolvers.hpp:116-122 "Block CG" with one column +
-// solve/NativePreconditioners.hpp:36-96).  Scalars live in a device array s: 0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>.
-// Every dot product is a two-stage reduction in a fixed order (bitwise reproducible for a given grid).
-constexpr int cg_threads = 256, cg_blocks = 1024;
-__device__ __forceinline__ double blockSum(double v, double* sh)
-{
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int w = cg_threads / 2; w > 0; w >>= 1)
-    {
-        if (threadIdx.x < w)
-            sh[threadIdx.x] += sh[threadIdx.x + w];
-        __syncthreads();
-    }
-    return sh[0];
-}
-__global__ __launch_bounds__(cg_threads) void cgDotKernel(const double* __restrict__ u, const double* __restrict__ v, int64_t n,
-                                                          double* __restrict__ partial)
-{
-    __shared__ double sh[cg_threads];
-    double            acc = 0.;
-    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
-        acc += u[i] * v[i];
-    const double t = blockSum(acc, sh);
-    if (threadIdx.x == 0)
-        partial[blockIdx.x] = t;
-}
-// s[dst0] = sum partial[0][:], s[dst1] = sum partial[1][:] (dst1 < 0: one row); shift != 0: s[0] = s[2] first
-__global__ __launch_bounds__(cg_threads) void cgFinishKernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ s,
-                                                             int dst0, int dst1, int shift)
-{
-    __shared__ double sh[cg_threads];
-    for (int row = 0; row < (dst1 >= 0 ? 2 : 1); ++row)
-    {
-        double acc = 0.;
-        for (int i = threadIdx.x; i < n_blocks; i += cg_threads)
-            acc += partial[row * n_blocks + i];
-        __syncthreads();
-        const double t = blockSum(acc, sh);
-        if (threadIdx.x == 0)
-            s[row == 0 ? dst0 : dst1] = t;
-    }
-    if (shift && threadIdx.x == 0)
-        s[0] = s[2];
-}
-// alpha = s[0]/s[1]; x += alpha p; r -= alpha Ap; partial <r, minv r>, <r, r>
-__global__ __launch_bounds__(cg_threads) void cgUpdateXRKernel(double* __restrict__ x, double* __restrict__ r,
-                                                               const double* __restrict__ p, const double* __restrict__ ap,
-                                                               const double* __restrict__ minv, int64_t n,
-                                                               const double* __restrict__ s, double* __restrict__ partial)
-{
-    __shared__ double sh[cg_threads];
-    const double      alpha = s[0] / s[1];
-    double            rz = 0., rr = 0.;
-    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
-    {
-        x[i] += alpha * p[i];
-        const double ri = r[i] - alpha * ap[i];
-        r[i]            = ri;
-        rz += ri * (minv ? minv[i] * ri : ri);
-        rr += ri * ri;
-    }
-    const double a = blockSum(rz, sh);
-    __syncthreads();
-    const double b = blockSum(rr, sh);
-    if (threadIdx.x == 0)
-    {
-        partial[blockIdx.x]             = a;
-        partial[gridDim.x + blockIdx.x] = b;
-    }
-}
-// beta = s[2]/s[0]; p = minv r + beta p
-__global__ __launch_bounds__(cg_threads) void cgUpdatePKernel(double* __restrict__ p, const double* __restrict__ r,
-                                                              const double* __restrict__ minv, int64_t n, const double* __restrict__ s)
-{
-    const double beta = s[2] / s[0];
-    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
-        p[i] = (minv ? minv[i] * r[i] : r[i]) + beta * p[i];
-}
-// r = b - r (r holds A x0 on entry); z-free start: p = minv r; partial <r, minv r>, <r, r>
-__global__ __launch_bounds__(cg_threads) void cgInitKernel(double* __restrict__ r, const double* __restrict__ b,
-                                                           double* __restrict__ p, const double* __restrict__ minv, int64_t n,
-                                                           double* __restrict__ partial)
-{
-    __shared__ double sh[cg_threads];
-    double            rz = 0., rr = 0.;
-    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
-    {
-        const double ri = b[i] - r[i];
-        const double zi = minv ? minv[i] * ri : ri;
-        r[i]            = ri;
-        p[i]            = zi;
-        rz += ri * zi;
-        rr += ri * ri;
-    }
-    const double a = blockSum(rz, sh);
-    __syncthreads();
-    const double c = blockSum(rr, sh);
-    if (threadIdx.x == 0)
-    {
-        partial[blockIdx.x]             = a;
-        partial[gridDim.x + blockIdx.x] = c;
-    }
-}
-// NativeJacobiImpl::init (solve/NativePreconditioners.hpp:75-96): sign(d) * damping / max(|d|, threshold)
-__global__ void jacobiInverseKernel(const double* __restrict__ d, int64_t n, double damping, double threshold, double* __restrict__ out)
-{
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-    {
-        const double v = d[i], a = fabs(v);
-        out[i]         = (v < 0. ? -damping : damping) / (a > threshold ? a : threshold);
-    }
-}
-// averageElementContributions (algsys/ComputeValuesAtNodes.hpp:112-154): entries nobody wrote keep their value
-__global__ void averageValuesKernel(const double* __restrict__ sum, const double* __restrict__ count, int64_t n, double* __restrict__ values)
-{
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
-        if (count[i] > 0.)
-            values[i] = sum[i] / count[i];
-}
-inline int cgGrid(int64_t n)
-{
-    const int64_t g = (n + cg_threads - 1) / cg_threads;
-    return int(g < 1 ? 1 : (g > cg_blocks ? cg_blocks : g));
-}
-inline unsigned gridFor(int64_t n, int block = 256)
-{
-    const int64_t g = (n + block - 1) / block;
-    return static_cast< unsigned >(g < 1 ? 1 : (g > 8192 ? 8192 : g));
-}
-
-template < typename T >
-struct DevBuf
-{
-    T*     ptr = nullptr;
-    size_t n   = 0;
-    DevBuf()   = default;
-    DevBuf(const DevBuf&)            = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf()
-    {
-        if (ptr)
-            (void)hipFree(ptr);
-    }
-    int upload(const T* host, size_t count, hipStream_t s)
-    {
-        n = count;
-        if (count == 0)
-            return 0;
-        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ptr), count * sizeof(T)));
-        L3K_HIP(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyHostToDevice, s));
-        return 0;
-    }
-};
 } // namespace
-
-// ------------------------------------------------------------------------------------------------ objects
-struct l3k_ctx
-{
-    int         device;
-    hipStream_t stream;
-    double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
-    ~l3k_ctx()
-    {
-        if (red_ws)
-            (void)hipFree(red_ws);
-    }
-};
-struct l3k_mesh
-{
-    l3k_ctx*            ctx;
-    int                 dim, order, dofs_per_node;
-    int64_t             n_elems, n_interior, n_owned_nodes, n_ghost_nodes;
-    DevBuf< uint32_t >  elem_nodes;
-    DevBuf< double >    elem_verts;
-    DevBuf< uint8_t >   dirichlet;
-    DevBuf< int64_t >   owned_dirichlet_rows;
-    DevBuf< uint8_t >   elem_flags;
-    int64_t             exclusive_begin = 0, exclusive_end = 0;
-    int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
-    int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
-};
-struct l3k_bnd;
-struct l3k_mf
-{
-    std::vector< l3k_bnd* > boundary_terms; // attached boundary equation kernels (not owned)
-    l3k_ctx*            ctx;
-    l3k_mesh*           mesh;
-    int                 kernel_id, nq, n_rhs;
-    l3k_kparams         kp;
-    std::vector< char > blob;
-    int                 field_inds[l3k::dev::max_unknowns];
-    DevBuf< double >    tables;
-    std::vector< double > tables_host;
-    const double*       fields = nullptr;
-    size_t              ldf    = 0;
-    double              time   = 0.;
-    bool                dense = false, fuse = false;
-    double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
-    size_t              ws_doubles = 0;
-    ~l3k_mf()
-    {
-        if (ws)
-            (void)hipFree(ws);
-    }
-};
-
-// a boundary equation kernel on a list of element sides (assembleProblem(kernel, boundary_ids) of the reference)
-struct l3k_bnd
-{
-    l3k_ctx*              ctx;
-    l3k_mesh*             mesh;
-    int                   kernel_id, nq, n_rhs;
-    l3k_kparams           kp;
-    std::vector< char >   blob;
-    int                   field_inds[l3k::dev::max_unknowns];
-    DevBuf< double >      tables;
-    DevBuf< int64_t >     face_elem; // sides of interior elements first
-    DevBuf< uint8_t >     face_side;
-    int64_t               n_faces = 0, n_interior_faces = 0;
-    const double*         fields = nullptr;
-    size_t                ldf    = 0;
-    double                time   = 0.;
-};
 
 namespace
 {
-struct KernelMeta
-{
-    int         id;
-    l3k_kparams kp;
-    const char* name;
-    size_t      bytes;
-    bool        boundary = false;
-};
 const std::vector< KernelMeta >& kernelMetas()
 {
     static const std::vector< KernelMeta > metas = [] {
@@ -410,6 +125,10 @@ const KernelMeta* fromPlugin(int id, bool residual)
                                                  residual}));
     return &seen.back()->meta;
 }
+} // namespace
+
+namespace l3k::api
+{
 const KernelMeta* findResidual(int id)
 {
     for (const auto& k : residualMetas())
@@ -424,6 +143,10 @@ const KernelMeta* findKernel(int id)
             return &k;
     return fromPlugin(id, false);
 }
+} // namespace l3k::api
+
+namespace
+{
 
 int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
 {
@@ -1401,371 +1124,4 @@ int l3k_mf_attach_boundary(l3k_mf* mf, l3k_bnd* bnd)
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ integrals
-int l3k_residual_info(int residual_id, l3k_kparams* params, const char** name, size_t* param_bytes)
-{
-    const auto* k = findResidual(residual_id);
-    if (!k)
-    {
-        setError("unknown residual kernel id %d", residual_id);
-        return -1;
-    }
-    if (params)
-        *params = k->kp;
-    if (name)
-        *name = k->name;
-    if (param_bytes)
-        *param_bytes = k->bytes;
-    return 0;
-}
-int l3k_integrate(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
-                  const l3k_asmopts* opts, const double* d_fields, size_t ldf, double time, int square, int64_t n_faces,
-                  const int64_t* face_elem, const uint8_t* face_side, double* h_out)
-{
-    if (!ctx || !mesh || !h_out || (n_faces > 0 && (!face_elem || !face_side)))
-    {
-        setError("l3k_integrate: bad argument");
-        return -1;
-    }
-    const auto* k = findResidual(residual_id);
-    if (!k)
-    {
-        setError("unknown residual kernel id %d", residual_id);
-        return -1;
-    }
-    if (k->kp.dimension != mesh->dim)
-    {
-        setError("kernel dimension %d != mesh dimension %d", k->kp.dimension, mesh->dim);
-        return -1;
-    }
-    if (kparam_blob && kparam_bytes != k->bytes)
-    {
-        setError("kernel %s expects a %zu-byte parameter block, got %zu", k->name, k->bytes, kparam_bytes);
-        return -1;
-    }
-    if (k->kp.n_fields > 0 && (!d_fields || ldf < size_t(mesh->n_owned_nodes + mesh->n_ghost_nodes)))
-    {
-        setError("kernel %s reads %d fields: pass them as SoA with ld >= number of local nodes", k->name, k->kp.n_fields);
-        return -1;
-    }
-    const bool side = n_faces >= 0;
-    for (int64_t i = 0; i < n_faces; ++i)
-        if (face_elem[i] < 0 || face_elem[i] >= mesh->n_elems || face_side[i] >= 6)
-        {
-            setError("side %lld = (element %lld, side %d) is outside the mesh", (long long)i, (long long)face_elem[i],
-                     int(face_side[i]));
-            return -1;
-        }
-    const int E = k->kp.n_equations;
-    for (int i = 0; i < E; ++i)
-        h_out[i] = 0.;
-    const int64_t count = side ? n_faces : mesh->n_elems;
-    if (count == 0)
-        return 0;
-    const l3k_asmopts o  = opts ? *opts : l3k_asmopts{1, 0, 0};
-    const int         nq = l3k_n_qps1d(mesh->order, o.value_order, o.derivative_order);
-    if (nq < mesh->order + 1)
-    {
-        setError("nq = %d < p+1 = %d: the collocation-derivative device algorithm needs nq >= p+1", nq, mesh->order + 1);
-        return -1;
-    }
-    const auto* inst = l3k::dev::findIntegralInstance(residual_id, mesh->order, nq);
-    if (!inst)
-    {
-        setError("no device instantiation for residual kernel %d, order %d, nq %d: add it to "
-                 "L3K_FOR_EACH_RESIDUAL_INSTANCE (l3ster_amd/csrc/user_kernels.hpp) and rebuild",
-                 residual_id, mesh->order, nq);
-        return -4;
-    }
-    L3K_HIP(hipSetDevice(ctx->device));
-    hipStream_t        s = ctx->stream;
-    DevBuf< double >   tables, partial;
-    DevBuf< int64_t >  fe;
-    DevBuf< uint8_t >  fs;
-    const auto         block = l3k::host::deviceTableBlock(mesh->order, nq);
-    if (int rc = tables.upload(block.data(), block.size(), s))
-        return rc;
-    if (side)
-    {
-        if (int rc = fe.upload(face_elem, size_t(n_faces), s))
-            return rc;
-        if (int rc = fs.upload(face_side, size_t(n_faces), s))
-            return rc;
-    }
-    partial.n = size_t(count + 1) * E; // [count][E] partial sums + [E] result
-    L3K_HIP(hipMalloc(reinterpret_cast< void** >(&partial.ptr), partial.n * sizeof(double)));
-    l3k::dev::ElemArgs a{};
-    a.elem_nodes = mesh->elem_nodes.ptr;
-    a.elem_verts = mesh->elem_verts.ptr;
-    a.tables     = tables.ptr;
-    a.fields     = d_fields;
-    a.ldf        = ldf;
-    a.time       = time;
-    a.elem_begin = 0, a.elem_count = mesh->n_elems;
-    a.face_elem = fe.ptr, a.face_side = fs.ptr, a.face_begin = 0, a.face_count = side ? n_faces : 0;
-    a.partial = partial.ptr;
-    a.square  = square;
-    if (int rc = (side ? inst->boundary : inst->domain)(a, kparam_blob, s))
-        return rc;
-    double* d_out = partial.ptr + size_t(count) * E;
-    hipLaunchKernelGGL(reducePartialsKernel, dim3(E), dim3(reduce_threads), 0, s, partial.ptr, count, E,
-                       d_out);
-    L3K_HIP(hipGetLastError());
-    L3K_HIP(hipMemcpyAsync(h_out, d_out, sizeof(double) * E, hipMemcpyDeviceToHost, s));
-    L3K_HIP(hipStreamSynchronize(s));
-    return 0;
-}
-// ------------------------------------------------------------------------------------------------ values at nodes
-int l3k_values_at_nodes(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const void* kparam_blob, size_t kparam_bytes,
-                        const double* d_fields, size_t ldf, double time, int64_t n_faces, const int64_t* face_elem,
-                        const uint8_t* face_side, const int* dof_inds, double* d_sum, double* d_count)
-{
-    if (!ctx || !mesh || !dof_inds || !d_sum || !d_count || (n_faces > 0 && (!face_elem || !face_side)))
-    {
-        setError("l3k_values_at_nodes: bad argument");
-        return -1;
-    }
-    const auto* k = findResidual(residual_id);
-    if (!k)
-    {
-        setError("unknown residual kernel id %d", residual_id);
-        return -1;
-    }
-    if (k->kp.dimension != mesh->dim || k->kp.n_equations > l3k::dev::max_unknowns)
-    {
-        setError("kernel %s does not fit this mesh (dimension %d, %d equations)", k->name, k->kp.dimension, k->kp.n_equations);
-        return -1;
-    }
-    if (kparam_blob && kparam_bytes != k->bytes)
-    {
-        setError("kernel %s expects a %zu-byte parameter block, got %zu", k->name, k->bytes, kparam_bytes);
-        return -1;
-    }
-    if (k->kp.n_fields > 0 && (!d_fields || ldf < size_t(mesh->n_owned_nodes + mesh->n_ghost_nodes)))
-    {
-        setError("kernel %s reads %d fields: pass them as SoA with ld >= number of local nodes", k->name, k->kp.n_fields);
-        return -1;
-    }
-    for (int e = 0; e < k->kp.n_equations; ++e)
-        if (dof_inds[e] < 0 || dof_inds[e] >= mesh->dofs_per_node)
-        {
-            setError("dof_inds[%d] = %d outside [0, dofs_per_node = %d)", e, dof_inds[e], mesh->dofs_per_node);
-            return -1;
-        }
-    for (int64_t i = 0; i < n_faces; ++i)
-        if (face_elem[i] < 0 || face_elem[i] >= mesh->n_elems || face_side[i] >= 6)
-        {
-            setError("side %lld = (element %lld, side %d) is outside the mesh", (long long)i, (long long)face_elem[i],
-                     int(face_side[i]));
-            return -1;
-        }
-    const bool    side  = n_faces >= 0;
-    const int64_t count = side ? n_faces : mesh->n_elems;
-    if (count == 0)
-        return 0;
-    const auto* inst = l3k::dev::findIntegralInstance(residual_id, mesh->order, -1);
-    if (!inst)
-    {
-        setError("no device instantiation for residual kernel %d, order %d: add it to L3K_FOR_EACH_RESIDUAL_INSTANCE "
-                 "(l3ster_amd/csrc/user_kernels.hpp) and rebuild", residual_id, mesh->order);
-        return -4;
-    }
-    L3K_HIP(hipSetDevice(ctx->device));
-    hipStream_t       s = ctx->stream;
-    DevBuf< double >  tables;
-    DevBuf< int64_t > fe;
-    DevBuf< uint8_t > fs;
-    const auto        block = l3k::host::deviceTableBlock(mesh->order, inst->nq);
-    if (int rc = tables.upload(block.data(), block.size(), s))
-        return rc;
-    if (side)
-    {
-        if (int rc = fe.upload(face_elem, size_t(n_faces), s))
-            return rc;
-        if (int rc = fs.upload(face_side, size_t(n_faces), s))
-            return rc;
-    }
-    l3k::dev::ElemArgs a{};
-    a.elem_nodes = mesh->elem_nodes.ptr;
-    a.elem_verts = mesh->elem_verts.ptr;
-    a.tables     = tables.ptr;
-    a.fields     = d_fields;
-    a.ldf        = ldf;
-    a.time       = time;
-    a.dofs_per_node = mesh->dofs_per_node;
-    a.elem_begin = 0, a.elem_count = mesh->n_elems;
-    a.face_elem = side ? fe.ptr : nullptr, a.face_side = fs.ptr, a.face_begin = 0, a.face_count = side ? n_faces : 0;
-    for (int e = 0; e < k->kp.n_equations; ++e)
-        a.field_inds[e] = dof_inds[e];
-    a.node_sum   = d_sum;
-    a.node_count = d_count;
-    if (int rc = inst->at_nodes(a, kparam_blob, s))
-        return rc;
-    L3K_HIP(hipStreamSynchronize(s)); // the staging buffers are released on return
-    return 0;
-}
-int l3k_average_values(l3k_ctx* ctx, const double* d_sum, const double* d_count, int64_t n, double* d_values)
-{
-    if (!ctx || (n > 0 && (!d_sum || !d_count || !d_values)))
-    {
-        setError("l3k_average_values: null argument");
-        return -1;
-    }
-    if (n > 0)
-        hipLaunchKernelGGL(averageValuesKernel, dim3(gridFor(n)), dim3(256), 0, ctx->stream, d_sum, d_count, n, d_values);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------ Jacobi-PCG
-static int cgWorkspace(l3k_ctx* ctx)
-{
-    if (!ctx->red_ws)
-        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ctx->red_ws), sizeof(double) * 2 * cg_blocks));
-    return 0;
-}
-int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv)
-{
-    if (!ctx || (n > 0 && (!d_diag || !d_minv)))
-    {
-        setError("l3k_jacobi_inverse: null argument");
-        return -1;
-    }
-    if (n > 0)
-        hipLaunchKernelGGL(jacobiInverseKernel, dim3(gridFor(n)), dim3(256), 0, ctx->stream, d_diag, n, damping, threshold, d_minv);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-int l3k_cg_init(l3k_ctx* ctx, double* d_r, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s)
-{
-    if (!ctx || !d_r || !d_b || !d_p || !d_s)
-    {
-        setError("l3k_cg_init: null argument");
-        return -1;
-    }
-    if (int rc = cgWorkspace(ctx))
-        return rc;
-    const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgInitKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_r, d_b, d_p, d_minv, n, ctx->red_ws);
-    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 2, 3, 1);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t n, double* d_s)
-{
-    if (!ctx || !d_p || !d_ap || !d_s)
-    {
-        setError("l3k_cg_dot_pap: null argument");
-        return -1;
-    }
-    if (int rc = cgWorkspace(ctx))
-        return rc;
-    const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgDotKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_ap, n, ctx->red_ws);
-    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 1, -1, 0);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
-                     int64_t n, double* d_s)
-{
-    if (!ctx || !d_x || !d_r || !d_p || !d_ap || !d_s)
-    {
-        setError("l3k_cg_update_xr: null argument");
-        return -1;
-    }
-    if (int rc = cgWorkspace(ctx))
-        return rc;
-    const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgUpdateXRKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_x, d_r, d_p, d_ap, d_minv, n, d_s, ctx->red_ws);
-    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 2, 3, 0);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s)
-{
-    if (!ctx || !d_p || !d_r || !d_s)
-    {
-        setError("l3k_cg_update_p: null argument");
-        return -1;
-    }
-    const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgUpdatePKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_r, d_minv, n, d_s);
-    // <r,z> of this iteration becomes the old one: after every block has read both
-    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, 0, d_s, 4, -1, 1);
-    L3K_HIP(hipGetLastError());
-    return 0;
-}
-int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_minv, const l3k_cg_opts* opts,
-                  l3k_cg_result* result)
-{
-    if (!mf || !d_b || !d_x || !result)
-    {
-        setError("l3k_pcg_solve: null argument");
-        return -1;
-    }
-    if (mf->mesh->n_ghost_nodes != 0)
-    {
-        setError("l3k_pcg_solve is the single-rank solver; partitioned systems iterate with the l3k_cg_* pieces and an "
-                 "all-reduce of the scalar block between them (l3ster_amd/solve.py)");
-        return -1;
-    }
-    const l3k_cg_opts o = opts ? *opts : l3k_cg_opts{1e-6, 10000, 0, 1};
-    l3k_ctx*          ctx = mf->ctx;
-    hipStream_t       st  = ctx->stream;
-    const int64_t     n   = mf->mesh->nOwnedDofs();
-    DevBuf< double >  work; // r | p | ap | s[8]
-    work.n = size_t(3 * n + 8);
-    L3K_HIP(hipMalloc(reinterpret_cast< void** >(&work.ptr), work.n * sizeof(double)));
-    double *r = work.ptr, *p = r + n, *ap = p + n, *s = ap + n;
-    double  h[4];
-    const auto scalars = [&]() -> int {
-        L3K_HIP(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
-        L3K_HIP(hipStreamSynchronize(st));
-        return 0;
-    };
-    // r = b - A x0, p = z = M^-1 r
-    if (int rc = l3k_mf_apply(mf, d_x, size_t(n), r, size_t(n), 1, 1., 0.))
-        return rc;
-    if (int rc = l3k_cg_init(ctx, r, d_b, p, d_minv, n, s))
-        return rc;
-    double scale = 1.;
-    if (o.residual_scaling == 2)
-    {
-        if (int rc = l3k_cg_dot_pap(ctx, d_b, d_b, n, s)) // s[1] = <b, b> (scratch use of the slot)
-            return rc;
-    }
-    if (int rc = scalars())
-        return rc;
-    const double rr0 = std::sqrt(h[3]);
-    if (o.residual_scaling == 1)
-        scale = rr0 > 0. ? rr0 : 1.;
-    else if (o.residual_scaling == 2)
-        scale = std::sqrt(h[1]) > 1e-300 ? std::sqrt(h[1]) : 1e-300;
-    double res = rr0 / scale;
-    int    it  = 0;
-    const int every = o.check_every > 0 ? o.check_every : 1;
-    while (res > o.tol && it < o.max_iters)
-    {
-        if (int rc = l3k_mf_apply(mf, p, size_t(n), ap, size_t(n), 1, 1., 0.))
-            return rc;
-        if (int rc = l3k_cg_dot_pap(ctx, p, ap, n, s))
-            return rc;
-        if (int rc = l3k_cg_update_xr(ctx, d_x, r, p, ap, d_minv, n, s))
-            return rc;
-        if (int rc = l3k_cg_update_p(ctx, p, r, d_minv, n, s))
-            return rc;
-        ++it;
-        if (it % every == 0 || it == o.max_iters)
-        {
-            if (int rc = scalars())
-                return rc;
-            res = std::sqrt(h[3]) / scale;
-        }
-    }
-    result->achieved_tol = res;
-    result->iterations   = it;
-    result->converged    = res <= o.tol;
-    return 0;
-}
 } // extern "C"

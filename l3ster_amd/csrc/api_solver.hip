@@ -1,0 +1,279 @@
+// api_solver.hip -- Jacobi-preconditioned conjugate gradients of libl3k.so: fused vector kernels and the single-rank driver.
+#include "objects.hpp"
+
+namespace
+{
+// ---- fused vector kernels of the Jacobi-PCG iteration (solve/BelosSolvers.hpp:116-122 "Block CG" with one column +
+// solve/NativePreconditioners.hpp:36-96).  Scalars live in a device array s: 0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>.
+// Every dot product is a two-stage reduction in a fixed order (bitwise reproducible for a given grid).
+constexpr int cg_threads = 256, cg_blocks = 1024;
+__device__ __forceinline__ double blockSum(double v, double* sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = cg_threads / 2; w > 0; w >>= 1)
+    {
+        if (threadIdx.x < w)
+            sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    return sh[0];
+}
+__global__ __launch_bounds__(cg_threads) void cgDotKernel(const double* __restrict__ u, const double* __restrict__ v, int64_t n,
+                                                          double* __restrict__ partial)
+{
+    __shared__ double sh[cg_threads];
+    double            acc = 0.;
+    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
+        acc += u[i] * v[i];
+    const double t = blockSum(acc, sh);
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = t;
+}
+// s[dst0] = sum partial[0][:], s[dst1] = sum partial[1][:] (dst1 < 0: one row); shift != 0: s[0] = s[2] first
+__global__ __launch_bounds__(cg_threads) void cgFinishKernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ s,
+                                                             int dst0, int dst1, int shift)
+{
+    __shared__ double sh[cg_threads];
+    for (int row = 0; row < (dst1 >= 0 ? 2 : 1); ++row)
+    {
+        double acc = 0.;
+        for (int i = threadIdx.x; i < n_blocks; i += cg_threads)
+            acc += partial[row * n_blocks + i];
+        __syncthreads();
+        const double t = blockSum(acc, sh);
+        if (threadIdx.x == 0)
+            s[row == 0 ? dst0 : dst1] = t;
+    }
+    if (shift && threadIdx.x == 0)
+        s[0] = s[2];
+}
+// alpha = s[0]/s[1]; x += alpha p; r -= alpha Ap; partial <r, minv r>, <r, r>
+__global__ __launch_bounds__(cg_threads) void cgUpdateXRKernel(double* __restrict__ x, double* __restrict__ r,
+                                                               const double* __restrict__ p, const double* __restrict__ ap,
+                                                               const double* __restrict__ minv, int64_t n,
+                                                               const double* __restrict__ s, double* __restrict__ partial)
+{
+    __shared__ double sh[cg_threads];
+    const double      alpha = s[0] / s[1];
+    double            rz = 0., rr = 0.;
+    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
+    {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * ap[i];
+        r[i]            = ri;
+        rz += ri * (minv ? minv[i] * ri : ri);
+        rr += ri * ri;
+    }
+    const double a = blockSum(rz, sh);
+    __syncthreads();
+    const double b = blockSum(rr, sh);
+    if (threadIdx.x == 0)
+    {
+        partial[blockIdx.x]             = a;
+        partial[gridDim.x + blockIdx.x] = b;
+    }
+}
+// beta = s[2]/s[0]; p = minv r + beta p
+__global__ __launch_bounds__(cg_threads) void cgUpdatePKernel(double* __restrict__ p, const double* __restrict__ r,
+                                                              const double* __restrict__ minv, int64_t n, const double* __restrict__ s)
+{
+    const double beta = s[2] / s[0];
+    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
+        p[i] = (minv ? minv[i] * r[i] : r[i]) + beta * p[i];
+}
+// r = b - r (r holds A x0 on entry); z-free start: p = minv r; partial <r, minv r>, <r, r>
+__global__ __launch_bounds__(cg_threads) void cgInitKernel(double* __restrict__ r, const double* __restrict__ b,
+                                                           double* __restrict__ p, const double* __restrict__ minv, int64_t n,
+                                                           double* __restrict__ partial)
+{
+    __shared__ double sh[cg_threads];
+    double            rz = 0., rr = 0.;
+    for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
+    {
+        const double ri = b[i] - r[i];
+        const double zi = minv ? minv[i] * ri : ri;
+        r[i]            = ri;
+        p[i]            = zi;
+        rz += ri * zi;
+        rr += ri * ri;
+    }
+    const double a = blockSum(rz, sh);
+    __syncthreads();
+    const double c = blockSum(rr, sh);
+    if (threadIdx.x == 0)
+    {
+        partial[blockIdx.x]             = a;
+        partial[gridDim.x + blockIdx.x] = c;
+    }
+}
+// NativeJacobiImpl::init (solve/NativePreconditioners.hpp:75-96): sign(d) * damping / max(|d|, threshold)
+__global__ void jacobiInverseKernel(const double* __restrict__ d, int64_t n, double damping, double threshold, double* __restrict__ out)
+{
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    {
+        const double v = d[i], a = fabs(v);
+        out[i]         = (v < 0. ? -damping : damping) / (a > threshold ? a : threshold);
+    }
+}
+inline int cgGrid(int64_t n)
+{
+    const int64_t g = (n + cg_threads - 1) / cg_threads;
+    return int(g < 1 ? 1 : (g > cg_blocks ? cg_blocks : g));
+}
+} // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ Jacobi-PCG
+static int cgWorkspace(l3k_ctx* ctx)
+{
+    if (!ctx->red_ws)
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ctx->red_ws), sizeof(double) * 2 * cg_blocks));
+    return 0;
+}
+int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv)
+{
+    if (!ctx || (n > 0 && (!d_diag || !d_minv)))
+    {
+        setError("l3k_jacobi_inverse: null argument");
+        return -1;
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(jacobiInverseKernel, dim3(gridFor(n)), dim3(256), 0, ctx->stream, d_diag, n, damping, threshold, d_minv);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_cg_init(l3k_ctx* ctx, double* d_r, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s)
+{
+    if (!ctx || !d_r || !d_b || !d_p || !d_s)
+    {
+        setError("l3k_cg_init: null argument");
+        return -1;
+    }
+    if (int rc = cgWorkspace(ctx))
+        return rc;
+    const int g = cgGrid(n);
+    hipLaunchKernelGGL(cgInitKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_r, d_b, d_p, d_minv, n, ctx->red_ws);
+    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 2, 3, 1);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t n, double* d_s)
+{
+    if (!ctx || !d_p || !d_ap || !d_s)
+    {
+        setError("l3k_cg_dot_pap: null argument");
+        return -1;
+    }
+    if (int rc = cgWorkspace(ctx))
+        return rc;
+    const int g = cgGrid(n);
+    hipLaunchKernelGGL(cgDotKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_ap, n, ctx->red_ws);
+    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 1, -1, 0);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
+                     int64_t n, double* d_s)
+{
+    if (!ctx || !d_x || !d_r || !d_p || !d_ap || !d_s)
+    {
+        setError("l3k_cg_update_xr: null argument");
+        return -1;
+    }
+    if (int rc = cgWorkspace(ctx))
+        return rc;
+    const int g = cgGrid(n);
+    hipLaunchKernelGGL(cgUpdateXRKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_x, d_r, d_p, d_ap, d_minv, n, d_s, ctx->red_ws);
+    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 2, 3, 0);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s)
+{
+    if (!ctx || !d_p || !d_r || !d_s)
+    {
+        setError("l3k_cg_update_p: null argument");
+        return -1;
+    }
+    const int g = cgGrid(n);
+    hipLaunchKernelGGL(cgUpdatePKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_r, d_minv, n, d_s);
+    // <r,z> of this iteration becomes the old one: after every block has read both
+    hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, 0, d_s, 4, -1, 1);
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
+int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_minv, const l3k_cg_opts* opts,
+                  l3k_cg_result* result)
+{
+    if (!mf || !d_b || !d_x || !result)
+    {
+        setError("l3k_pcg_solve: null argument");
+        return -1;
+    }
+    if (mf->mesh->n_ghost_nodes != 0)
+    {
+        setError("l3k_pcg_solve is the single-rank solver; partitioned systems iterate with the l3k_cg_* pieces and an "
+                 "all-reduce of the scalar block between them (l3ster_amd/solve.py)");
+        return -1;
+    }
+    const l3k_cg_opts o = opts ? *opts : l3k_cg_opts{1e-6, 10000, 0, 1};
+    l3k_ctx*          ctx = mf->ctx;
+    hipStream_t       st  = ctx->stream;
+    const int64_t     n   = mf->mesh->nOwnedDofs();
+    DevBuf< double >  work; // r | p | ap | s[8]
+    work.n = size_t(3 * n + 8);
+    L3K_HIP(hipMalloc(reinterpret_cast< void** >(&work.ptr), work.n * sizeof(double)));
+    double *r = work.ptr, *p = r + n, *ap = p + n, *s = ap + n;
+    double  h[4];
+    const auto scalars = [&]() -> int {
+        L3K_HIP(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
+        L3K_HIP(hipStreamSynchronize(st));
+        return 0;
+    };
+    // r = b - A x0, p = z = M^-1 r
+    if (int rc = l3k_mf_apply(mf, d_x, size_t(n), r, size_t(n), 1, 1., 0.))
+        return rc;
+    if (int rc = l3k_cg_init(ctx, r, d_b, p, d_minv, n, s))
+        return rc;
+    double scale = 1.;
+    if (o.residual_scaling == 2)
+    {
+        if (int rc = l3k_cg_dot_pap(ctx, d_b, d_b, n, s)) // s[1] = <b, b> (scratch use of the slot)
+            return rc;
+    }
+    if (int rc = scalars())
+        return rc;
+    const double rr0 = std::sqrt(h[3]);
+    if (o.residual_scaling == 1)
+        scale = rr0 > 0. ? rr0 : 1.;
+    else if (o.residual_scaling == 2)
+        scale = std::sqrt(h[1]) > 1e-300 ? std::sqrt(h[1]) : 1e-300;
+    double res = rr0 / scale;
+    int    it  = 0;
+    const int every = o.check_every > 0 ? o.check_every : 1;
+    while (res > o.tol && it < o.max_iters)
+    {
+        if (int rc = l3k_mf_apply(mf, p, size_t(n), ap, size_t(n), 1, 1., 0.))
+            return rc;
+        if (int rc = l3k_cg_dot_pap(ctx, p, ap, n, s))
+            return rc;
+        if (int rc = l3k_cg_update_xr(ctx, d_x, r, p, ap, d_minv, n, s))
+            return rc;
+        if (int rc = l3k_cg_update_p(ctx, p, r, d_minv, n, s))
+            return rc;
+        ++it;
+        if (it % every == 0 || it == o.max_iters)
+        {
+            if (int rc = scalars())
+                return rc;
+            res = std::sqrt(h[3]) / scale;
+        }
+    }
+    result->achieved_tol = res;
+    result->iterations   = it;
+    result->converged    = res <= o.tol;
+    return 0;
+}
+} // extern "C"

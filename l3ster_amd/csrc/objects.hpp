@@ -1,0 +1,161 @@
+// objects.hpp -- the objects behind the opaque handles of include/l3k.h and the helpers the api_*.hip files share.
+#ifndef L3K_OBJECTS_HPP
+#define L3K_OBJECTS_HPP
+
+#include "l3k.h"
+
+#include "device/common.hpp"
+#include "host/tables.hpp"
+#include "user_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <type_traits>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace l3k::dev
+{
+const char* lastError();
+}
+using l3k::dev::setError;
+
+#define L3K_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t err_ = (call);                                                                                \
+        if (err_ != hipSuccess)                                                                                        \
+        {                                                                                                              \
+            setError("%s failed: %s (%s:%d)", #call, hipGetErrorString(err_), __FILE__, __LINE__);                     \
+            return -3;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+
+
+namespace l3k::api
+{
+inline unsigned gridFor(int64_t n, int block = 256)
+{
+    const int64_t g = (n + block - 1) / block;
+    return static_cast< unsigned >(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+template < typename T >
+struct DevBuf
+{
+    T*     ptr = nullptr;
+    size_t n   = 0;
+    DevBuf()   = default;
+    DevBuf(const DevBuf&)            = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+    }
+    int upload(const T* host, size_t count, hipStream_t s)
+    {
+        n = count;
+        if (count == 0)
+            return 0;
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ptr), count * sizeof(T)));
+        L3K_HIP(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+};
+} // namespace l3k::api
+using l3k::api::DevBuf;
+using l3k::api::gridFor;
+
+struct l3k_ctx
+{
+    int         device;
+    hipStream_t stream;
+    double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
+    ~l3k_ctx()
+    {
+        if (red_ws)
+            (void)hipFree(red_ws);
+    }
+};
+struct l3k_mesh
+{
+    l3k_ctx*            ctx;
+    int                 dim, order, dofs_per_node;
+    int64_t             n_elems, n_interior, n_owned_nodes, n_ghost_nodes;
+    DevBuf< uint32_t >  elem_nodes;
+    DevBuf< double >    elem_verts;
+    DevBuf< uint8_t >   dirichlet;
+    DevBuf< int64_t >   owned_dirichlet_rows;
+    DevBuf< uint8_t >   elem_flags;
+    int64_t             exclusive_begin = 0, exclusive_end = 0;
+    int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
+    int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
+};
+struct l3k_bnd;
+struct l3k_mf
+{
+    std::vector< l3k_bnd* > boundary_terms; // attached boundary equation kernels (not owned)
+    l3k_ctx*            ctx;
+    l3k_mesh*           mesh;
+    int                 kernel_id, nq, n_rhs;
+    l3k_kparams         kp;
+    std::vector< char > blob;
+    int                 field_inds[l3k::dev::max_unknowns];
+    DevBuf< double >    tables;
+    std::vector< double > tables_host;
+    const double*       fields = nullptr;
+    size_t              ldf    = 0;
+    double              time   = 0.;
+    bool                dense = false, fuse = false;
+    double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
+    size_t              ws_doubles = 0;
+    ~l3k_mf()
+    {
+        if (ws)
+            (void)hipFree(ws);
+    }
+};
+
+// a boundary equation kernel on a list of element sides (assembleProblem(kernel, boundary_ids) of the reference)
+struct l3k_bnd
+{
+    l3k_ctx*              ctx;
+    l3k_mesh*             mesh;
+    int                   kernel_id, nq, n_rhs;
+    l3k_kparams           kp;
+    std::vector< char >   blob;
+    int                   field_inds[l3k::dev::max_unknowns];
+    DevBuf< double >      tables;
+    DevBuf< int64_t >     face_elem; // sides of interior elements first
+    DevBuf< uint8_t >     face_side;
+    int64_t               n_faces = 0, n_interior_faces = 0;
+    const double*         fields = nullptr;
+    size_t                ldf    = 0;
+    double                time   = 0.;
+};
+
+
+namespace l3k::api
+{
+struct KernelMeta
+{
+    int         id;
+    l3k_kparams kp;
+    const char* name;
+    size_t      bytes;
+    bool        boundary = false;
+};
+// registered equation kernels (built in or announced by a plugin) / residual kernels by id; nullptr if unknown
+const KernelMeta* findKernel(int id);
+const KernelMeta* findResidual(int id);
+} // namespace l3k::api
+#endif
