@@ -8,7 +8,7 @@
 // collocation matrix on the Gauss points -- the LDS footprint is O(nq^2 n) instead of O(nq^3).
 //
 // One element (or side) per workgroup; each workgroup writes E partial sums, reduced in a fixed order by
-// reducePartialsKernel in api.hip (bitwise reproducible results).
+// reducePartialsKernel in api_post.hip (bitwise reproducible results).
 #ifndef L3K_DEVICE_INTEGRAL_HPP
 #define L3K_DEVICE_INTEGRAL_HPP
 
