@@ -29,6 +29,9 @@ from l3ster_amd.distributed import DistributedOperator, HaloPlan  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+# executed FP64 flops per element of sumfactFastKernel<Diffusion3D> (ISA count: (fma + fmac) * 2 + mul + add, times the
+# active lanes per element): order 6: 4 460 lane-flops x 49 lanes
+FP64_FLOP_PER_ELEM = {6: 4460 * 49}
 
 
 def algorithmic_bytes_per_dof(p, U, F=0):
@@ -132,7 +135,7 @@ def main():
 
     def step(i=None):
         if op is not None:
-            op.apply(X, Y, 1.0, 0.0)
+            op.apply(X, Y, 1.0, 0.0, events=None if i is None else (ev0[i], ev1[i]))
         elif i is None:
             mf.apply(X, Y, 1.0, 0.0)
         else:  # same three launches as l3k_mf_apply, with events around the element kernel
@@ -175,16 +178,27 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "setup_s": round(t_setup, 2)},
     }
     if rank == 0:
+        # the dominant kernel launch of rank 0: all elements (one GPU) or the interior elements (partitioned), HIP events
+        # on the launch stream inside the timed region; algorithmic bytes = 17.81 B per dof of the elements it processes
+        ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        n_launch_elems = part.n_interior_elems if op is not None else part.n_elems
+        launch_dofs = n_launch_elems * p ** 3 * U if op is not None else global_dofs
+        alg_bytes = bpd * launch_dofs
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        flop_per_elem = FP64_FLOP_PER_ELEM.get(p)
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": measured_traffic(args.ne, p) if world == 1 else None,
+                              "kernel": "sumfactFastKernel" + (" (interior elements of rank 0)" if op is not None else ""),
+                              "kernel_ms": ms, "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
+                              "algorithmic_bytes_per_launch": alg_bytes,
+                              "fp64_note": "the kernel is FP64-VALU bound, not HBM bound (DESIGN.md 4.1): executed vector "
+                                           "FP64 flops per element from the ISA, peak = 78.6 TFLOP/s spec (57.5 measured, "
+                                           "tools/fp64_peak.hip); the FP64 ceiling of this instruction stream is ~30 % of "
+                                           "the HBM roofline",
+                              "fp64_tflops": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12,
+                              "fp64_peak_tflops": 78.6}
         if world == 1 and op is None:
-            ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-            alg_bytes = bpd * global_dofs
-            achieved = alg_bytes / (ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.ne, p),
-                                  "kernel": "sumfactFastKernel", "kernel_ms": ms, "bytes_per_dof": bpd,
-                                  "dofs_per_launch": global_dofs, "algorithmic_bytes_per_launch": alg_bytes,
-                                  "fp64_note": "the kernel is FP64-VALU/LDS bound, not HBM bound (DESIGN.md): measured "
-                                               "vector FP64 peak 57.5 TFLOP/s (tools/fp64_peak.hip)"}
             if not args.no_cpu_baseline:
                 base, (spart, smask, sx, sy) = cpu_baseline(p, U)
                 result["cpu_baseline"] = base
