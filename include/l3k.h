@@ -135,6 +135,9 @@ int l3k_mf_set_time(l3k_mf* mf, double time);
  * without ghosts (n_ghost_nodes == 0): scale (:1038), gather with Dirichlet -> 0 (:421-467), sum-factorised element
  * kernel (algsys/SumFactorization.hpp:882-917), scatter-add skipping Dirichlet dofs (:494-537), y[d] += alpha*x[d] on
  * owned Dirichlet rows (:1087-1098).  ncols <= n_rhs, else error (:1035-1037). */
+/* Alignment: when the kernel's unknowns are all dofs of a node (the dense layout), x, y and the ghost buffers must be
+ * 16-byte aligned and leading dimensions even when ncols > 1 (a node's dofs move with 16-byte accesses); align node rows
+ * to 32 bytes for full speed. */
 int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha,
                  double beta);
 

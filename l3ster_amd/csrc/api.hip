@@ -735,6 +735,19 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         setError("mesh has ghost nodes: border elements need the ghost import/export buffers");
         return -1;
     }
+    // the kernels move a node's dofs with 16-byte accesses (and run 18 % slower when a node's row straddles a 32-byte
+    // boundary: profiles/r01_kbench_vector_alignment.log)
+    const auto misaligned = [](const void* p, size_t ld, int nc) {
+        return reinterpret_cast< uintptr_t >(p) % 16 != 0 || (nc > 1 && (ld * sizeof(double)) % 16 != 0);
+    };
+    if (mf->dense && // (the generic kernel behind non-dense dof layouts uses 8-byte accesses)
+        (misaligned(d_x, ldx, ncols) || misaligned(d_y, ldy, ncols) ||
+         (m->n_ghost_nodes > 0 && d_xghost && misaligned(d_xghost, ldxg, ncols)) ||
+         (m->n_ghost_nodes > 0 && d_yghost && misaligned(d_yghost, ldyg, ncols))))
+    {
+        setError("vectors must be 16-byte aligned (columns too: even leading dimensions); 32-byte alignment is faster");
+        return -1;
+    }
     a.x     = d_x;
     a.xg    = d_xghost;
     a.y     = d_y;
