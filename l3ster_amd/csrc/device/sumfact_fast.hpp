@@ -119,6 +119,9 @@ __device__ __forceinline__ void stageFence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef L3K_FAST_MIN_WAVES
+#define L3K_FAST_MIN_WAVES 2
+#endif
 template < typename K, int P, int NQ >
 struct FastCfg
 {
@@ -138,13 +141,14 @@ struct FastCfg
     static constexpr int    TEAM_D   = 2 * BUF_D + 24;
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D;
     static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUF_D && U % 2 == 0;
+    // resident single-wave workgroups per CU by LDS capacity; with at most one per SIMD the wave may use all 512
+    // registers (VGPR + AGPR) of its SIMD lane instead of spilling to scratch (order 7: 33 KB of LDS per wave)
+    static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
+    static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : L3K_FAST_MIN_WAVES;
 };
 
-#ifndef L3K_FAST_MIN_WAVES
-#define L3K_FAST_MIN_WAVES 2
-#endif
 template < typename K, int P, int NQ >
-__global__ __launch_bounds__(64, L3K_FAST_MIN_WAVES) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
+__global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
     using Cfg = FastCfg< K, P, NQ >;
