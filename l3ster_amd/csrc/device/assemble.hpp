@@ -125,8 +125,12 @@ struct GemmCfg
     static constexpr size_t lds = sizeof(double) * (2 * KC * LDS_ROW + QC * CSP + 2 * N1 * NQ);
 };
 
+#ifndef L3K_GEMM_MIN_BLOCKS
+#define L3K_GEMM_MIN_BLOCKS 2
+#endif
+// two workgroups per CU (LDS: 69 KB each): one generates its Z chunk while the other runs its MFMAs; needs <= 256 registers
 template < typename K, int P, int NQ >
-__global__ __launch_bounds__(256) void assembleGemmKernel(const ElemArgs a, const double* __restrict__ cbuf, int64_t elem0)
+__global__ __launch_bounds__(256, L3K_GEMM_MIN_BLOCKS) void assembleGemmKernel(const ElemArgs a, const double* __restrict__ cbuf, int64_t elem0)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
