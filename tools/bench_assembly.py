@@ -25,8 +25,10 @@ a = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
 p, U, E = a.order, 4, 7
-part = system.CubePartition(4, p, perturb=0.1)  # 64 elements
-assert part.n_elems >= a.batch
+ne = 4
+while ne ** 3 < a.batch:
+    ne += 1
+part = system.CubePartition(ne, p, perturb=0.1)  # at least `batch` elements
 mesh = system.DeviceMesh(ctx, part, U)
 mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 1.0])
 mf.local_assemble(0, a.batch, want_K=a.store, want_F=False, want_checksum=True)  # warm-up
