@@ -36,12 +36,32 @@ L3K_FOR_EACH_RESIDUAL_KERNEL(L3K_X)
 
 namespace l3k::dev
 {
-// single-column applies use the register-resident pipelined kernel when its working set fits
+// R columns through the one-wave-per-element kernel, one column per launch: at order 6 it is ~3x faster per column than
+// the generic LDS kernel, so R launches beat one R-column launch (the apply never reads the kernel's rhs, so the
+// single-column instantiation of the functor gives the same operator); other dof layouts go to the generic kernel
+template < typename T, int P, int NQ, int R >
+int launchColumnsFast(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    if (!a.dense)
+        return launchSumfactApply< T, P, NQ, R, false >(a, kparam_blob, stream);
+    for (int c = 0; c < R; ++c)
+    {
+        ElemArgs ac = a;
+        ac.x        = a.x + a.ldx * c;
+        ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
+        ac.y        = a.y + a.ldy * c;
+        ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
+        if (int rc = launchSumfactFast< T, P, NQ >(ac, kparam_blob, stream))
+            return rc;
+    }
+    return 0;
+}
+// applies use the register-resident pipelined kernel when its working set fits
 template < typename T, int P, int NQ, int R >
 constexpr LaunchFn selectApply()
 {
-    if constexpr (R == 1 && FastCfg< T, P, NQ >::feasible)
-        return &launchSumfactFast< T, P, NQ >;
+    if constexpr (FastCfg< T, P, NQ >::feasible)
+        return R == 1 ? &launchSumfactFast< T, P, NQ > : &launchColumnsFast< T, P, NQ, R >;
     else
         return &launchSumfactApply< T, P, NQ, R, false >;
 }

@@ -207,14 +207,16 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
     auto       loadIds    = [&](int batch, uint32_t (&ids)[N1], uint32_t& flag) {
         flag = 0;
+        // "element touches a Dirichlet dof": every live lane of the team needs it (the scatter runs over all of them, not
+        // only over the N1*N1 lanes that gather); fetched with the ids, one element ahead of its use
+        if (have_flags && batch < last && (int64_t(batch) * EW + team) < a.elem_count)
+            flag = a.elem_flags[elemOf(batch)];
         if (valid(batch))
         {
             const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + i1 + N1 * j1;
 #pragma unroll
             for (int k = 0; k < N1; ++k)
                 ids[k] = en[k * N1 * N1];
-            if (have_flags) // "element touches a Dirichlet dof": fetched with the ids, one element ahead of its use
-                flag = a.elem_flags[elemOf(batch)];
         }
     };
     auto loadX = [&](int batch, const uint32_t (&ids)[N1], bool flagged) {

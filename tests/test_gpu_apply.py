@@ -76,6 +76,8 @@ MESH_CASES = [
     (system.KERNEL_DIFFUSION3D, 2, 5, 1, 1, 0.1),
     (system.KERNEL_DIFFUSION3D, 3, 6, 1, 1, 0.1),
     (system.KERNEL_DIFFUSION3D_VAR, 2, 3, 2, 2, 0.1),
+    (system.KERNEL_DIFFUSION3D_VAR, 2, 3, 2, 1, 0.1),  # more quadrature points than nodes per direction, one column
+    (system.KERNEL_DIFFUSION3D, 3, 3, 2, 1, 0.1),
     (system.KERNEL_DIFFUSION3D_VAR, 3, 4, 1, 1, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 2, 1, 2, 0.1),
     (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1, 0.1),
