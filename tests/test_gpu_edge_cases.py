@@ -88,29 +88,44 @@ def test_argument_errors_are_reported(S, ctx):
         S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0])
 
 
-@pytest.mark.parametrize("seed", range(12))
+def _single_column_shapes(S):
+    """(order, nq, (value_order, derivative_order)) of every compiled single-column Diffusion3D instantiation"""
+    out = []
+    for kid, p, nq, nc in S.instances():
+        if kid != S.KERNEL_DIFFUSION3D or nc != 1:
+            continue
+        opts = [(vo, do) for vo in range(1, 4) for do in range(0, 3) if S.n_qps1d(p, vo, do) == nq]
+        if opts:
+            out.append((p, nq, opts[0]))
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("seed", range(16))
 def test_randomised_apply_and_diag_rhs_parity(S, ctx, seed):
-    """Seeded random problems: element counts, order, distortion, Dirichlet dofs anywhere (any unknown, interior nodes
-    included), alpha / beta, columns -- apply, diagonal and lifted rhs against the oracle."""
+    """Seeded random problems over every compiled single-column shape (orders 1-8, quadrature sizes equal to and larger
+    than the node count): element counts, distortion, Dirichlet dofs anywhere (any unknown, interior nodes included),
+    alpha / beta -- apply, diagonal and lifted rhs against the oracle."""
     import oracle_lib as O
     rng = np.random.default_rng(1000 + seed)
-    p = int(rng.integers(1, 7))
-    ne = tuple(int(v) for v in rng.integers(1, 4 if p > 3 else 5, size=3))
+    shapes = _single_column_shapes(S)
+    p, nq, (vo, do) = shapes[seed % len(shapes)]
+    ne = tuple(int(v) for v in rng.integers(1, 3 if p > 5 else (4 if p > 3 else 5), size=3))
     U = 4
     part = S.CubePartition(ne, p, perturb=float(rng.uniform(0, 0.15)))
     mask = (rng.uniform(size=part.n_local_nodes * U) < rng.choice([0.0, 0.02, 0.2])).astype(np.uint8)
-    mesh = S.DeviceMesh(ctx, part, U, mask if mask.any() or seed % 2 else None)
+    use_mask = bool(mask.any() or seed % 2)
+    mesh = S.DeviceMesh(ctx, part, U, mask if use_mask else None)
     kp = [float(rng.uniform(0.5, 2)), float(rng.uniform(-1, 1))]
-    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, kp)
-    om = helpers.oracle_mesh(part, p + 1, U, np.arange(U), mask if mask.any() or seed % 2 else None)
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, kp, asm_opts=(vo, do, 0))
+    om = helpers.oracle_mesh(part, nq, U, np.arange(U), mask if use_mask else None)
     alpha, beta = float(rng.uniform(-2, 2)), float(rng.choice([0.0, 1.0, rng.uniform(-1, 1)]))
     x = rng.standard_normal((1, part.n_local_nodes * U))
     y0 = rng.standard_normal(x.shape)
     Y = torch.as_tensor(y0, device="cuda").clone()
     mf.apply(torch.as_tensor(x, device="cuda"), Y, alpha, beta)
     want = O.mf_apply(om, O.KERNEL_DIFFUSION3D, x.T, np.asfortranarray(y0.T.copy()), alpha=alpha, beta=beta, kparams=kp)
-    assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-11, (p, ne)
+    assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-11, (p, nq, ne)
     g = np.where(mask != 0, rng.standard_normal(mask.size), 0.0)[None, :]
     diag, rhs = mf.diag_rhs(torch.as_tensor(g, device="cuda"))
     wd, wr = O.mf_diag_rhs(om, O.KERNEL_DIFFUSION3D, dirichlet_vals=np.asfortranarray(g.T), kparams=kp)
-    assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-11 and helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-10, (p, ne)
+    assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-11 and helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-10, (p, nq, ne)
