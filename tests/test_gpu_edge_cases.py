@@ -129,3 +129,27 @@ def test_randomised_apply_and_diag_rhs_parity(S, ctx, seed):
     diag, rhs = mf.diag_rhs(torch.as_tensor(g, device="cuda"))
     wd, wr = O.mf_diag_rhs(om, O.KERNEL_DIFFUSION3D, dirichlet_vals=np.asfortranarray(g.T), kparams=kp)
     assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-11 and helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-10, (p, nq, ne)
+
+
+def test_small_launch_routing(S, ctx, monkeypatch):
+    """Default routing: a mesh below the small-launch threshold goes through the generic LDS kernel, above it through the
+    one-wave-per-element kernel; both agree with the oracle and with each other."""
+    import oracle_lib as O
+    p, U = 6, 4
+    part = S.CubePartition(3, p, perturb=0.1)  # 27 elements
+    mask = part.dirichlet_mask(U)
+    mesh = S.DeviceMesh(ctx, part, U, mask)
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    x = part.synthetic_vector(U)
+    want = O.mf_apply(helpers.oracle_mesh(part, p + 1, U, np.arange(U), mask), O.KERNEL_DIFFUSION3D, x.T, kparams=[1.0, 1.0])
+    out = {}
+    for name, value in (("generic", None), ("fast", "0")):
+        if value is None:
+            monkeypatch.delenv("L3K_GENERIC_BELOW", raising=False)  # product default: 768
+        else:
+            monkeypatch.setenv("L3K_GENERIC_BELOW", value)
+        Y = torch.zeros((1, part.n_local_nodes * U), dtype=torch.float64, device="cuda")
+        mf.apply(torch.as_tensor(x, device="cuda"), Y)
+        out[name] = Y.cpu().numpy()
+        assert helpers.rel_err(out[name].T, want) < 1e-12, name
+    assert not np.array_equal(out["generic"], out["fast"])  # different kernels: different rounding
