@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # the live parity sample below (8^3 elements) must run the kernel that is being timed, not the small-launch route
+    os.environ["L3K_GENERIC_BELOW"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
