@@ -1,7 +1,10 @@
 #!/bin/bash
-# element-order experiment: brick size of the mesh traversal vs kernel time (order 6 and 4, 64^3)
-for b in 1 2 4 8 16; do
-  echo "== L3K_MESH_BRICK=$b"
-  L3K_MESH_BRICK=$b timeout -k 10 200 python tools/kbench.py --order 6 --ne 64 --steps 5 --flags 0 --child || exit 1
-  L3K_MESH_BRICK=$b timeout -k 10 200 python tools/kbench.py --order 4 --ne 64 --steps 5 --flags 0 --child || exit 1
+# Mesh-traversal experiment behind the default brick edges (l3ster_amd/csrc/host/cube_mesh.cpp:brickEdge): kernel time vs
+# brick edge for orders 6 and 4 on ne^3 elements.  Usage: tools/brick_sweep.sh [ne=64] [edges...]
+ne=${1:-64}; shift
+edges=${@:-1 2 4 5 6 7 8 9 10 12 16 20 24 32}
+for b in $edges; do
+  echo "== L3K_MESH_BRICK=$b ne=$ne"
+  L3K_MESH_BRICK=$b timeout -k 10 200 python tools/kbench.py --order 6 --ne $ne --steps 5 --flags 0 --child || exit 1
+  L3K_MESH_BRICK=$b timeout -k 10 200 python tools/kbench.py --order 4 --ne $ne --steps 5 --flags 0 --child || exit 1
 done
