@@ -144,6 +144,7 @@ struct FastCfg
     // resident single-wave workgroups per CU by LDS capacity; with at most one per SIMD the wave may use all 512
     // registers (VGPR + AGPR) of its SIMD lane instead of spilling to scratch (order 7: 33 KB of LDS per wave)
     static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
+    // (three waves per SIMD for the small-LDS shapes was tried: 168 registers, spills, order 4 5.1 -> 7.5 ns per element)
     static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : L3K_FAST_MIN_WAVES;
 };
 
@@ -763,7 +764,7 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         n_cus = prop.multiProcessorCount;
         // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the 256-VGPR budget (2 per SIMD)
         int by_lds = int((160 * 1024) / Cfg::lds);
-        waves_cu   = by_lds < 1 ? 1 : (by_lds > 8 ? 8 : by_lds);
+        waves_cu   = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::min_waves ? 4 * Cfg::min_waves : by_lds);
         if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
             waves_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_cu;
         attr_set = true;
