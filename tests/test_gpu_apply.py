@@ -274,3 +274,55 @@ def test_multi_rank_schedule_on_one_gpu(ctx, ne, p, parts, ncols):
         ref = y_ref.reshape(whole.n_local_nodes, U, ncols)[rows]
         got = y.reshape(ncols, len(rows), U).transpose(1, 2, 0)
         assert np.linalg.norm(got - ref) < 1e-11 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("ne,p", [(64, 6), (64, 4)])
+def test_operator_properties_at_full_size(ctx, ne, p):
+    """BASELINE.json's single-GPU sizes (64^3 elements, orders 6 and 4: 228 M / 68 M dofs), through properties that do not
+    need the oracle on the whole mesh: self-adjointness, linearity, positive semi-definiteness; the exact linear
+    field T = x, q = (1, 0, 0) (in the discrete space whatever the distortion) is annihilated by the interior rows of the
+    source-free operator; and the rows of the elements of one brick agree with the oracle run on those elements alone."""
+    U = 4
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 0.0])
+    x = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=1)
+    z = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=2)
+    Ax, Az, Axz = torch.empty_like(x), torch.empty_like(z), torch.empty_like(x)
+    mf.apply(x, Ax)
+    mf.apply(z, Az)
+    s1, s2 = torch.dot(Ax[0], z[0]).item(), torch.dot(x[0], Az[0]).item()
+    assert abs(s1 - s2) < 1e-11 * max(abs(s1), 1.0)
+    assert torch.dot(Ax[0], x[0]).item() > 0
+    z.mul_(2.0).add_(x)
+    mf.apply(z, Axz)
+    Az.mul_(2.0).add_(Ax)
+    assert (Axz - Az).norm().item() < 1e-12 * Axz.norm().item()
+    del Az, Axz, z
+    # exact linear solution: B u = 0 at every quadrature point, so A u vanishes on all rows that are not Dirichlet rows
+    # (the gather reads Dirichlet dofs as 0, so rows of elements touching the boundary are excluded)
+    coords = torch.as_tensor(part.node_coords()[:, 0], device="cuda")
+    u = torch.zeros((part.n_local_nodes, U), dtype=torch.float64, device="cuda")
+    u[:, 0], u[:, 1] = coords, 1.0
+    Au = torch.empty_like(x)
+    mf.apply(u.view(1, -1), Au)
+    touched = np.zeros(part.n_local_nodes, bool)
+    touched[part.elem_nodes[part.elem_boundary != 0].reshape(-1)] = True
+    inner = torch.as_tensor(~touched, device="cuda")
+    assert Au.view(-1, U)[inner].abs().max().item() < 1e-9 * Ax.abs().max().item()
+    # oracle on a sample: the 216 elements of the first brick, rows of nodes touched by those elements only
+    sample = np.arange(min(216, part.n_elems))
+    sub = O.MeshView(3, p, p + 1, part.elem_nodes[sample], part.elem_verts[sample], part.n_local_nodes, U, np.arange(U), mask)
+    xs = x.cpu().numpy()
+    ys = O.mf_apply(sub, 0, xs.T, kparams=[1.0, 0.0], do_dirichlet_rows=False)
+    # rows whose every contributing element is in the sample: nodes interior to the sampled block
+    count_all = np.zeros(part.n_local_nodes, np.int32)
+    np.add.at(count_all, part.elem_nodes.reshape(-1), 1)
+    count_sub = np.zeros(part.n_local_nodes, np.int32)
+    np.add.at(count_sub, part.elem_nodes[sample].reshape(-1), 1)
+    complete = np.nonzero((count_sub > 0) & (count_sub == count_all))[0]
+    rows = (complete[:, None] * U + np.arange(U)[None, :]).reshape(-1)
+    rows = rows[mask[rows] == 0]
+    assert len(rows) > 1000
+    assert rel_err(Ax.cpu().numpy()[0, rows], ys[rows, 0]) < 1e-11
