@@ -200,6 +200,29 @@ def main():
                                            "the HBM roofline",
                               "fp64_tflops": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12,
                               "fp64_peak_tflops": 78.6}
+        if world == 1 and op is None and p == 6:
+            # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly (K_e = B^T W B on the FP64
+            # matrix cores), order 6, streaming mode (checksums instead of 15 MB per matrix); outside the timed region
+            batch, reps = 512, 3
+            apart = system.CubePartition(8, p, perturb=0.1)
+            amesh = system.DeviceMesh(ctx, apart, U)
+            amf = system.MatrixFreeSystem(amesh, kid, [1.0, 1.0])
+            amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(reps):
+                amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
+            a1.record()
+            torch.cuda.synchronize()
+            ams = a0.elapsed_time(a1) / reps
+            nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * 7
+            rate = batch / (ams * 1e-3)
+            result["assembled_path"] = {"metric": "element-matrices/s for assembled path (LocalAssembly, Diffusion3D, hex p=6)",
+                                        "value": rate, "unit": "element matrices/s", "batch": batch,
+                                        "roofline": {"bound": "mfma", "achieved": rate * kd * nd * (nd + 1) / 1e12, "peak": 78.6,
+                                                     "unit": "TFLOP/s", "frac": rate * kd * nd * (nd + 1) / 1e12 / 78.6,
+                                                     "flops": "symmetric half, 2*K*N*(N+1)/2 per element"}}
+            del amf, amesh, apart
         if world == 1 and op is None:
             if not args.no_cpu_baseline:
                 base, (spart, smask, sx, sy) = cpu_baseline(p, U)
