@@ -122,6 +122,17 @@ __device__ __forceinline__ void stageFence()
 #ifndef L3K_FAST_MIN_WAVES
 #define L3K_FAST_MIN_WAVES 2
 #endif
+// A kernel that never reads in.field_ders may say so (static constexpr bool field_derivatives = false): the derivative
+// sweeps of the external fields and their half of the second LDS buffer are then skipped
+template < typename K >
+constexpr bool kernelUsesFieldDers()
+{
+    if constexpr (requires { K::field_derivatives; })
+        return K::field_derivatives;
+    else
+        return true;
+}
+
 template < typename K, int P, int NQ >
 struct FastCfg
 {
@@ -137,10 +148,14 @@ struct FastCfg
 #endif
     static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
     // per team: bufA | bufB (NG groups of OS double2 each) | vertices
-    static constexpr int    BUF_D    = 2 * NG * OS;
-    static constexpr int    TEAM_D   = 2 * BUF_D + 24;
+    // groups whose reference derivatives reach the quadrature-point stage: all of them, or the unknowns' only
+    static constexpr int    DG       = kernelUsesFieldDers< K >() ? NG : UG;
+    static constexpr int    DF       = kernelUsesFieldDers< K >() ? NF : U; // fields with derivatives
+    static constexpr int    BUF_D    = 2 * NG * OS;                         // buffer A (doubles)
+    static constexpr int    BUFB_D   = 2 * DG * OS;                         // buffer B: derivative groups only
+    static constexpr int    TEAM_D   = BUF_D + BUFB_D + 24;
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D;
-    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUF_D && U % 2 == 0;
+    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUFB_D && U % 2 == 0;
     // resident single-wave workgroups per CU by LDS capacity; with at most one per SIMD the wave may use all 512
     // registers (VGPR + AGPR) of its SIMD lane instead of spilling to scratch (order 7: 33 KB of LDS per wave)
     static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
@@ -155,6 +170,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     using Cfg = FastCfg< K, P, NQ >;
     constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
+    constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
+    // with fewer derivative groups than groups, buffer B is too small for the y / x interpolation of all groups: those two
+    // sweeps then run in place in buffer A (a lane reads its whole pencil before it writes it; pencils are disjoint)
+    constexpr bool INPLACE = DG < NG;
     auto          at = [](int c, int b, int a_) { return a_ * PS + b * M + c; };
 
     extern __shared__ double lds[];
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     double* const            base = lds + size_t(team) * Cfg::TEAM_D;
     double2* const           bufA = reinterpret_cast< double2* >(base);
     double2* const           bufB = reinterpret_cast< double2* >(base + Cfg::BUF_D);
-    double* const            vs   = base + 2 * Cfg::BUF_D; // [8][3]
+    double* const            vs   = base + Cfg::BUF_D + Cfg::BUFB_D; // [8][3]
 
     const double* const eoI  = tab.eoI;
     const double* const eoC  = tab.eoC;
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 sweepEO< N1, NQ, false, false >(in1, o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    stg(bufB, g, at(iq, q, kq), o0[q], o1[q]);
+                    stg(INPLACE ? bufA : bufB, g, at(iq, q, kq), o0[q], o1[q]);
             }
         }
         stageFence();
@@ -352,7 +371,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
                 {
-                    const double2 t = ldg(bufB, g, at(i, qa, qb));
+                    const double2 t = ldg(INPLACE ? bufA : bufB, g, at(i, qa, qb));
                     in0[i] = t.x;
                     in1[i] = t.y;
                 }
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             }
             const double* tC = eoC + opaqueZero();
 #pragma unroll
-            for (int o = 0; o < NF; ++o)
+            for (int o = 0; o < DF; ++o)
             {
                 double in[NQ], der[NQ];
 #pragma unroll
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             const double* tC = eoC + opaqueZero();
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < DG; ++g)
             {
                 double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             const double* tC = eoC + opaqueZero();
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < DG; ++g)
             {
                 double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double vv[NF], dv[3][NF], r0[U], rd[3][U];
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
+                for (int g = 0; g < DG; ++g)
                 {
                     const double2 te = ldg(bufB, g, at(q, qa, qb)), tz = ldg(bufA, g, at(q, qa, qb));
                     dv[1][2 * g] = te.x;
@@ -452,8 +471,11 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #pragma unroll
                 for (int o = 0; o < NF; ++o)
                 {
-                    vv[o]    = v[q][o];
-                    dv[0][o] = dxi[q][o];
+                    vv[o] = v[q][o];
+                    if (o < DF)
+                        dv[0][o] = dxi[q][o];
+                    else // the kernel declared that it never reads the derivatives of the external fields
+                        dv[0][o] = dv[1][o] = dv[2][o] = 0.;
                 }
                 qpStage< K, 1, false >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd);
 #pragma unroll

@@ -90,6 +90,8 @@ struct Diffusion3DVar
 struct AdvDiff3D
 {
     static constexpr KernelParams params{.dimension = 3, .n_equations = 7, .n_unknowns = 4, .n_fields = 3};
+    // the velocity enters by value only: lets the device kernels skip the derivative sweeps of the three fields
+    static constexpr bool         field_derivatives = false;
     double                        k = 1., sigma = 1., s = 1.;
 
     template < typename In, typename Out >
