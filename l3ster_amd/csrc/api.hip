@@ -145,6 +145,31 @@ const KernelMeta* findKernel(int id)
 }
 } // namespace l3k::api
 
+#ifdef L3K_ABLATION
+// stage timeline of the single-wave kernel (tools/kbench.py --stamps): 256 iterations x 16 cycle counters of workgroup 0
+namespace
+{
+constexpr int n_stamps = 256 * 16;
+long long*    debugStamps()
+{
+    static long long* buf = [] {
+        long long* p = nullptr;
+        if (std::getenv("L3K_STAMPS") && hipMalloc(&p, n_stamps * sizeof(long long)) == hipSuccess)
+            (void)hipMemset(p, 0, n_stamps * sizeof(long long));
+        return p;
+    }();
+    return buf;
+}
+} // namespace
+extern "C" int l3k_debug_stamps(long long* host, int n)
+{
+    long long* p = debugStamps();
+    if (!p || n > n_stamps)
+        return -1;
+    return hipMemcpy(host, p, n * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
 namespace
 {
 
@@ -158,6 +183,8 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.elem_flags      = m->elem_flags.ptr;
     a.exclusive_node_begin = m->exclusive_begin;
     a.exclusive_node_end   = m->exclusive_end;
+    a.slot_tab             = m->slot_tab.ptr;
+    a.n_shell              = m->n_shell;
     a.tables          = mf->tables.ptr;
     a.tables_host     = mf->tables_host.data();
     a.fields          = mf->fields;
@@ -170,6 +197,11 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
         return e ? std::atoi(e) : 0;
     }();
     a.dbg   = dbg_flags;
+#ifdef L3K_ABLATION
+    a.stamps = debugStamps();
+#else
+    a.stamps = nullptr;
+#endif
     a.dense = mf->dense;
     for (int u = 0; u < l3k::dev::max_unknowns; ++u)
         a.field_inds[u] = mf->field_inds[u];
@@ -543,6 +575,52 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
             --b;
         m->exclusive_begin = b;
         m->exclusive_end   = d->n_owned_nodes;
+        // The single-wave kernel decides "exclusive" by the LOCAL position (element-internal or not) instead of testing
+        // every node id: shrink the range until it holds no node that sits on an element's shell, and drop it altogether
+        // if some element-internal node lies outside it (numberings that do not put the internal nodes last).
+        const int n1 = d->order + 1;
+        auto      internal = [&](int64_t i) {
+            const int ix = int(i % n1), iy = int((i / n1) % n1), iz = int(i / (n1 * n1));
+            return ix > 0 && ix < n1 - 1 && iy > 0 && iy < n1 - 1 && iz > 0 && iz < n1 - 1;
+        };
+        int64_t max_shell = -1, min_internal = n_nodes;
+        for (int64_t e = 0; e < d->n_elems; ++e)
+            for (int64_t i = 0; i < N; ++i)
+            {
+                const int64_t id = d->elem_nodes[e * N + i];
+                if (internal(i))
+                    min_internal = std::min(min_internal, id);
+                else if (id < d->n_owned_nodes)
+                    max_shell = std::max(max_shell, id);
+            }
+        m->exclusive_begin = std::max(m->exclusive_begin, max_shell + 1);
+        if (d->n_elems == 0 || d->order < 2 || min_internal < m->exclusive_begin)
+            m->exclusive_begin = m->exclusive_end; // empty: every node is scattered with atomics
+        // scatter slots: local nodes of a typical element (the middle one of the traversal) in ascending id order --
+        // rows that are contiguous in y become contiguous slots; internal positions last
+        if (d->n_elems > 0 && n1 <= 8)
+        {
+            const uint32_t*        ids = d->elem_nodes + (d->n_elems / 2) * N;
+            std::vector< int32_t > order(static_cast< size_t >(N));
+            for (int64_t i = 0; i < N; ++i)
+                order[i] = int32_t(i);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                const bool ix = internal(x), iy = internal(y);
+                return ix != iy ? iy : ids[x] < ids[y];
+            });
+            std::vector< uint16_t > tab(static_cast< size_t >(n1 * n1 * 8), 0);
+            int                     n_shell = 0;
+            for (int64_t s = 0; s < N; ++s)
+            {
+                const int32_t i                           = order[s];
+                tab[(i % (n1 * n1)) * 8 + i / (n1 * n1)] = uint16_t(s);
+                n_shell += !internal(i);
+            }
+            m->n_shell = n_shell;
+            if (int rc = m->slot_tab.upload(tab.data(), tab.size(), ctx->stream))
+                return rc;
+            L3K_HIP(hipStreamSynchronize(ctx->stream)); // (tab is a local)
+        }
     }
     std::vector< int64_t > rows;
     std::vector< uint8_t > flags; // host staging buffers must outlive the stream synchronisation below

@@ -70,6 +70,8 @@ struct ElemArgs
     int64_t         elem_begin, elem_count;
     double          alpha, beta, time;
     int             fuse_beta; // rows of exclusive nodes are written as alpha*A*x + beta*y by the element kernel
+    const uint16_t* slot_tab;  // single-wave kernel: [ (p+1)^2 ][8] scatter slots of a lane's local nodes (objects.hpp:l3k_mesh)
+    int             n_shell;   // slots [0, n_shell) are scattered with atomics, [n_shell, N) are exclusive nodes (plain stores)
     int             dofs_per_node;
     int             field_inds[max_unknowns];
     // diag/rhs mode
@@ -86,6 +88,7 @@ struct ElemArgs
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
+    long long* stamps; // L3K_ABLATION builds with env L3K_STAMPS: per-stage cycle counters of workgroup 0 ([iteration][16])
     // boundary terms / integrals: element sides [face_begin, face_begin + face_count) of the list (device arrays)
     const int64_t* face_elem;
     const uint8_t* face_side;

@@ -107,8 +107,31 @@ struct FastTables
 __device__ __forceinline__ int opaqueZero()
 {
     int z;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z) : : "memory"); // ("memory": the stage's LDS reads stay behind the table loads)
     return z;
+}
+// A copy of a per-lane value the compiler cannot see through (keeps values derived from it out of loop-invariant hoisting).
+__device__ __forceinline__ int opaqueCopy(int x)
+{
+    int y;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+__device__ __forceinline__ double opaqueCopy(double x)
+{
+    double y;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+// Copies a 1-D table out of the kernel-argument segment (scalar loads) and pins the loads in front of everything that
+// follows in program order, so that their latency overlaps with the stage's LDS reads instead of following it.
+template < int N >
+__device__ __forceinline__ void loadTable(double (&t)[N], const double* src)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        t[i] = src[i];
+    __builtin_amdgcn_sched_barrier(0);
 }
 // Stage separator inside a wave: LDS instructions of one wave execute in issue order, so no s_barrier is needed; this
 // only stops the COMPILER from moving LDS accesses across the stage boundary.
@@ -118,6 +141,26 @@ __device__ __forceinline__ void stageFence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Stage timeline of one wave (tools/kbench.py --stamps; ablation builds only): shader clock at the stage boundaries of
+// workgroup 0, 16 slots per element iteration
+#ifdef L3K_ABLATION
+#define L3K_STAMP(k)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (a.stamps != nullptr && blockIdx.x == 0 && stamp_it < 256)                                                  \
+        {                                                                                                              \
+            const long long t_ = __builtin_readcyclecounter();                                                         \
+            if (lane == 0)                                                                                             \
+                a.stamps[stamp_it * 16 + (k)] = t_;                                                                    \
+        }                                                                                                              \
+    } while (0)
+#else
+#define L3K_STAMP(k)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+    } while (0)
+#endif
 
 #ifndef L3K_FAST_MIN_WAVES
 #define L3K_FAST_MIN_WAVES 2
@@ -154,8 +197,11 @@ struct FastCfg
     static constexpr int    BUF_D    = 2 * NG * OS;                         // buffer A (doubles)
     static constexpr int    BUFB_D   = 2 * DG * OS;                         // buffer B: derivative groups only
     static constexpr int    TEAM_D   = BUF_D + BUFB_D + 24;
-    static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D;
-    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUFB_D && U % 2 == 0;
+    static constexpr int    SLOT_B   = 16 * N1 * N1; // scatter-slot table of the mesh: [N1*N1 lanes][8] uint16, one copy per wave
+    static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D + SLOT_B;
+    static constexpr int    SG       = (64 / EW) / U * U; // lanes that scatter one element (the team's lanes + helpers): a multiple of U
+    static constexpr int    NSH      = NN - (N1 - 2) * (N1 - 2) * (N1 - 2); // nodes on the element's shell
+    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUFB_D && U % 2 == 0 && N1 <= 8 && SG >= U;
     // resident single-wave workgroups per CU by LDS capacity; with at most one per SIMD the wave may use all 512
     // registers (VGPR + AGPR) of its SIMD lane instead of spilling to scratch (order 7: 33 KB of LDS per wave)
     static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
@@ -171,6 +217,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
+    constexpr int HN = (N1 + 1) / 2, HQ = (NQ + 1) / 2;
     // with fewer derivative groups than groups, buffer B is too small for the y / x interpolation of all groups: those two
     // sweeps then run in place in buffer A (a lane reads its whole pencil before it writes it; pencils are disjoint)
     constexpr bool INPLACE = DG < NG;
@@ -179,10 +226,11 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     extern __shared__ double lds[];
     const int                lane = threadIdx.x;
     const int                team = lane / TEAM, l = lane - team * TEAM;
-    const bool               live = team < EW;
-    if (!live || l >= cmax(N1 * N1, cmax(N1 * NQ, NQ * NQ)))
-        return; // single-wave workgroup without barriers: idle lanes simply retire, EXEC stays fixed from here on
-    double* const            base = lds + size_t(team) * Cfg::TEAM_D;
+    // single-wave workgroup without barriers.  Lanes beyond the teams' pencils do no sweeps but help in the scatter:
+    // the 64 / EW lanes [steam * SG, (steam + 1) * SG) scatter the element of team `steam`
+    const bool               worker = team < EW && l < cmax(N1 * N1, cmax(N1 * NQ, NQ * NQ));
+    constexpr int            SG     = Cfg::SG;
+    double* const            base = lds + size_t(worker ? team : 0) * Cfg::TEAM_D;
     double2* const           bufA = reinterpret_cast< double2* >(base);
     double2* const           bufB = reinterpret_cast< double2* >(base + Cfg::BUF_D);
     double* const            vs   = base + Cfg::BUF_D + Cfg::BUFB_D; // [8][3]
@@ -196,11 +244,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 
     // pencil coordinates of this lane in the different stage grids (first index fastest)
     const int  i1 = l % N1, j1 = l / N1; // (N1 x N1) grid: gather / z-sweep / final z-sweep
-    const bool on_nn = N1 == NQ ? true : l < N1 * N1;
+    const bool on_nn = worker && (N1 == NQ ? true : l < N1 * N1);
     const int  iq = l % N1, kq = l / N1; // (N1 x NQ) grid: y-sweeps at node-x
-    const bool on_nq = N1 == NQ ? true : l < N1 * NQ;
     const int  qa = l % NQ, qb = l / NQ; // (NQ x NQ) grid
-    const bool on_qq = N1 == NQ ? true : l < NQ * NQ;
 
     // field-group accessors: group g holds fields 2g, 2g+1 (the second may be unused padding)
     auto ldg = [&](const double2* buf, int g, int idx) { return buf[g * OS + idx]; };
@@ -223,24 +269,34 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     uint32_t      dm_nxt[N1];
     const int64_t n_owned_nodes = a.n_owned_dofs / U;
     auto          elemOf = [&](int b) { return a.elem_begin + int64_t(b) * EW + team; };
-    auto          valid  = [&](int b) { return b < last && on_nn && (int64_t(b) * EW + team) < a.elem_count; };
+    auto          valid  = [&](int b) { return (b < last) & on_nn & ((int64_t(b) * EW + team) < a.elem_count); };
     const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
     auto       loadIds    = [&](int batch, uint32_t (&ids)[N1], uint32_t& flag) {
-        flag = 0;
-        // "element touches a Dirichlet dof": every live lane of the team needs it (the scatter runs over all of them, not
-        // only over the N1*N1 lanes that gather); fetched with the ids, one element ahead of its use
-        if (have_flags && batch < last && (int64_t(batch) * EW + team) < a.elem_count)
-            flag = a.elem_flags[elemOf(batch)];
+        // "element touches a Dirichlet dof", fetched with the ids, one element ahead of its use: bit 0 for the element this
+        // lane gathers (its team's), bit 1 for the element it scatters (the one of its scatter group steam)
+        // (per-lane addresses rebuilt from an opaque copy of the lane id: see the scatter)
+        const int lane_o = opaqueCopy(lane), steam = lane_o / SG;
+        uint32_t  fg = 0, fs = 0;
+        if (have_flags && batch < last)
+        {
+            if (steam < EW && (int64_t(batch) * EW + steam) < a.elem_count)
+                fs = a.elem_flags[a.elem_begin + int64_t(batch) * EW + steam];
+            if constexpr (EW == 1)
+                fg = fs;
+            else if (worker && (int64_t(batch) * EW + team) < a.elem_count)
+                fg = a.elem_flags[elemOf(batch)];
+        }
+        flag = (fg != 0 ? 1u : 0u) | (fs != 0 ? 2u : 0u);
         if (valid(batch))
         {
-            const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + i1 + N1 * j1;
+            const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + (lane_o - team * TEAM); // + i1 + N1 * j1
 #pragma unroll
             for (int k = 0; k < N1; ++k)
                 ids[k] = en[k * N1 * N1];
         }
     };
-    auto loadX = [&](int batch, const uint32_t (&ids)[N1], bool flagged) {
-        if (!valid(batch))
+    auto loadX = [&](bool mine, const uint32_t (&ids)[N1], bool flagged) {
+        if (!mine)
             return;
         // node-interleaved dofs with the kernel's unknowns = all dofs of a node (the launcher sends every other layout
         // to the generic kernel): 16-byte vector loads, adjacent lanes read adjacent nodes
@@ -276,20 +332,31 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     const double eta_l = qp[qa < NQ ? qa : 0], zeta_l = qp[qb < NQ ? qb : 0];
     const double wyz_l = qw[qa < NQ ? qa : 0] * qw[qb < NQ ? qb : 0];
 
+    // the mesh's scatter-slot table: one 16-byte row (8 x uint16) per gathering lane, kept in LDS behind the teams' buffers
+    uint4* const slotRows = reinterpret_cast< uint4* >(lds + size_t(EW) * Cfg::TEAM_D);
+    if (lane < N1 * N1)
+        slotRows[lane] = reinterpret_cast< const uint4* >(a.slot_tab)[lane];
+    stageFence();
     uint32_t flag_cur, flag_nxt = 0;
     loadIds(batch, ids_cur, flag_cur);
 
+    [[maybe_unused]] int stamp_it = 0;
     for (; batch < last; batch += stride)
     {
+        L3K_STAMP(0);
         // this team has an element in this batch (always, with one element per wave: batch < last <= elem_count)
         const bool act = (int64_t(batch) * EW + team) < a.elem_count;
+        // one mask per pencil grid; with N1 == NQ they are the same value, so that the stages form one masked region
+        const bool w_all = worker & act;
+        const bool w_nn = N1 == NQ ? w_all : (w_all & (l < N1 * N1)), w_nq = N1 == NQ ? w_all : (w_all & (l < N1 * NQ)),
+                   w_qq = N1 == NQ ? w_all : (w_all & (l < NQ * NQ));
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
-        loadX(batch, ids_cur, flag_cur != 0);
+        loadX(w_nn, ids_cur, (flag_cur & 1u) != 0);
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
         double u0[N1][2 * NG];
-        if (on_nn && act)
+        if (w_nn)
         {
 #pragma unroll
             for (int k = 0; k < N1; ++k)
@@ -297,7 +364,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     u0[k][u] = xn[k][u];
-                if (flag_cur != 0) // wave-uniform: only elements touching a Dirichlet dof pay for the masking
+                if ((flag_cur & 1u) != 0) // only elements touching a Dirichlet dof pay for the masking
                 {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -310,14 +377,15 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     u0[k][NF] = 0.;
             }
         }
-        if (act)
-            for (int t = l; t < 24; t += TEAM)
+        if (w_all)
+            for (int t = opaqueCopy(l); t < 24; t += TEAM)
                 vs[t] = a.elem_verts[elemOf(batch) * 24 + t];
 
         // ---- S1: z interpolation in registers; write (c=i, b=j, a=qz) into bufA
-        if (on_nn && act)
+        if (w_nn)
         {
-            const double* tI = eoI + opaqueZero();
+            double tI[2 * HN * HQ];
+            loadTable(tI, eoI + opaqueZero());
 #pragma unroll
             for (int g = 0; g < NG; ++g)
             {
@@ -336,47 +404,59 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             }
         }
         stageFence();
+        L3K_STAMP(1);
         // ---- S2: y interpolation, lane (i, qz): bufA (c=i, b=j, a=qz) -> bufB (c=i, b=qy, a=qz)
-        if (on_nq && act)
+        // (here and in the later LDS -> LDS stages the reads of all field groups are issued before the first group's
+        // sweeps: one exposed LDS round trip per stage instead of one per group)
+        if (w_nq)
         {
-            const double* tI = eoI + opaqueZero();
+            double tI[2 * HN * HQ];
+            loadTable(tI, eoI + opaqueZero());
+            double        in0[NG][N1], in1[NG][N1];
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-            {
-                double in0[N1], in1[N1], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
                 {
                     const double2 t = ldg(bufA, g, at(iq, j, kq));
-                    in0[j] = t.x;
-                    in1[j] = t.y;
+                    in0[g][j] = t.x;
+                    in1[g][j] = t.y;
                 }
-                sweepEO< N1, NQ, false, false >(in0, o0, tI);
-                sweepEO< N1, NQ, false, false >(in1, o1, tI);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                double o0[NQ], o1[NQ];
+                sweepEO< N1, NQ, false, false >(in0[g], o0, tI);
+                sweepEO< N1, NQ, false, false >(in1[g], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(INPLACE ? bufA : bufB, g, at(iq, q, kq), o0[q], o1[q]);
             }
         }
         stageFence();
+        L3K_STAMP(2);
         // ---- S3/S4: x interpolation + xi-derivative, lane (qy, qz) = (qa, qb); values to bufA (c=qx, b=qy, a=qz)
         double v[NQ][2 * NG], dxi[NQ][2 * NG];
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double* tI = eoI + opaqueZero();
+            double tI[2 * HN * HQ];
+            loadTable(tI, eoI + opaqueZero());
+            double        in0[NG][N1], in1[NG][N1];
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-            {
-                double in0[N1], in1[N1], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
                 {
                     const double2 t = ldg(INPLACE ? bufA : bufB, g, at(i, qa, qb));
-                    in0[i] = t.x;
-                    in1[i] = t.y;
+                    in0[g][i] = t.x;
+                    in1[g][i] = t.y;
                 }
-                sweepEO< N1, NQ, false, false >(in0, o0, tI);
-                sweepEO< N1, NQ, false, false >(in1, o1, tI);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                double o0[NQ], o1[NQ];
+                sweepEO< N1, NQ, false, false >(in0[g], o0, tI);
+                sweepEO< N1, NQ, false, false >(in1[g], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
@@ -385,7 +465,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     stg(bufA, g, at(q, qa, qb), o0[q], o1[q]);
                 }
             }
-            const double* tC = eoC + opaqueZero();
+            double tC[2 * HQ * HQ];
+            loadTable(tC, eoC + opaqueZero());
 #pragma unroll
             for (int o = 0; o < DF; ++o)
             {
@@ -400,56 +481,67 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             }
         }
         stageFence();
+        L3K_STAMP(3);
         // ---- S5: eta-derivative, lane (qx, qz) = (qa, qb): y-pencils of bufA -> bufB
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double* tC = eoC + opaqueZero();
+            double tC[2 * HQ * HQ];
+            loadTable(tC, eoC + opaqueZero());
+            double in0[DG][NQ], in1[DG][NQ];
 #pragma unroll
             for (int g = 0; g < DG; ++g)
-            {
-                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(qa, q, qb));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    in0[g][q] = t.x;
+                    in1[g][q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, false >(in0, o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1, o1, tC);
+#pragma unroll
+            for (int g = 0; g < DG; ++g)
+            {
+                double o0[NQ], o1[NQ];
+                sweepEO< NQ, NQ, true, false >(in0[g], o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1[g], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
             }
         }
         stageFence();
+        L3K_STAMP(4);
         // ---- S6: zeta-derivative in place in bufA, lane (qx, qy) = (qa, qb)
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double* tC = eoC + opaqueZero();
+            double tC[2 * HQ * HQ];
+            loadTable(tC, eoC + opaqueZero());
+            double in0[DG][NQ], in1[DG][NQ];
 #pragma unroll
             for (int g = 0; g < DG; ++g)
-            {
-                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(qa, qb, q));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    in0[g][q] = t.x;
+                    in1[g][q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, false >(in0, o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1, o1, tC);
+#pragma unroll
+            for (int g = 0; g < DG; ++g)
+            {
+                double o0[NQ], o1[NQ];
+                sweepEO< NQ, NQ, true, false >(in0[g], o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1[g], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
             }
         }
         stageFence();
+        L3K_STAMP(5);
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double wyz = wyz_l;
+            const double wyz = opaqueCopy(wyz_l); // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers)
             double       G[6][3];
             hexPencilGeom(vs, eta_l, zeta_l, G);
 #pragma unroll
@@ -493,45 +585,50 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             }
         }
         stageFence();
+        L3K_STAMP(6);
         // ---- S8: C^T along eta in place in bufB (lane (qx,qz)); S9: C^T along zeta in place in bufA (lane (qx,qy))
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double* tCt = eoCt + opaqueZero();
+            double tCt[2 * HQ * HQ];
+            loadTable(tCt, eoCt + opaqueZero());
 #pragma unroll
             for (int g = 0; g < UG; ++g)
             {
-                double in0[NQ], in1[NQ], o0[NQ], o1[NQ];
+                // both pencils of the group are read before the first is swept (disjoint buffers)
+                double e0[NQ], e1[NQ], z0[NQ], z1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufB, g, at(qa, q, qb));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    e0[q] = t.x;
+                    e1[q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, false >(in0, o0, tCt);
-                sweepEO< NQ, NQ, true, false >(in1, o1, tCt);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(qa, qb, q));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    z0[q] = t.x;
+                    z1[q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, false >(in0, o0, tCt);
-                sweepEO< NQ, NQ, true, false >(in1, o1, tCt);
+                sweepEO< NQ, NQ, true, false >(e0, o0, tCt);
+                sweepEO< NQ, NQ, true, false >(e1, o1, tCt);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
+                sweepEO< NQ, NQ, true, false >(z0, o0, tCt);
+                sweepEO< NQ, NQ, true, false >(z1, o1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
             }
         }
         stageFence();
+        L3K_STAMP(7);
         // ---- x-pencil (qy,qz): w = r0 + C^T r1 + g2 + g3, then I^T along x -> bufB (c=ix, b=qy, a=qz)
-        if (on_qq && act)
+        if (w_qq)
         {
-            const double* tCt = eoCt + opaqueZero();
+            double tCt[2 * HQ * HQ];
+            loadTable(tCt, eoCt + opaqueZero());
 #pragma unroll
             for (int g = 0; g < UG; ++g)
             {
@@ -554,7 +651,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     v[q][2 * g + 1] = w1[q];
                 }
             }
-            const double* tIt = eoIt + opaqueZero();
+            double tIt[2 * HQ * HN];
+            loadTable(tIt, eoIt + opaqueZero());
 #pragma unroll
             for (int g = 0; g < UG; ++g)
             {
@@ -573,176 +671,195 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             }
         }
         stageFence();
+        L3K_STAMP(8);
         // ---- I^T along y, lane (ix, qz) = (iq, kq): bufB (c=ix, b=qy, a=qz) -> bufA (c=ix, b=iy, a=qz)
-        if (on_nq && act)
+        if (w_nq)
         {
-            const double* tIt = eoIt + opaqueZero();
+            double tIt[2 * HQ * HN];
+            loadTable(tIt, eoIt + opaqueZero());
+            double in0[UG][NQ], in1[UG][NQ];
 #pragma unroll
             for (int g = 0; g < UG; ++g)
-            {
-                double in0[NQ], in1[NQ], o0[N1], o1[N1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufB, g, at(iq, q, kq));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    in0[g][q] = t.x;
+                    in1[g][q] = t.y;
                 }
-                sweepEO< NQ, N1, false, false >(in0, o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1, o1, tIt);
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+            {
+                double o0[N1], o1[N1];
+                sweepEO< NQ, N1, false, false >(in0[g], o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1[g], o1, tIt);
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
                     stg(bufA, g, at(iq, j, kq), o0[j], o1[j]);
             }
         }
         stageFence();
+        L3K_STAMP(9);
         // ---- I^T along z in registers, lane (ix, iy) = (i1, j1); stage the result in bufB as [node][unknown]
-        if (on_nn && act)
+        if (w_nn)
         {
-            const double* tIt = eoIt + opaqueZero();
+            double tIt[2 * HQ * HN];
+            loadTable(tIt, eoIt + opaqueZero());
             double*       sb  = reinterpret_cast< double* >(bufB);
+            const uint4   srow = slotRows[l]; // scatter slots of this lane's N1 nodes
+            const uint32_t sw[4] = {srow.x, srow.y, srow.z, srow.w};
+            double in0[UG][NQ], in1[UG][NQ];
 #pragma unroll
             for (int g = 0; g < UG; ++g)
-            {
-                double in0[NQ], in1[NQ], o0[N1], o1[N1];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(i1, j1, q));
-                    in0[q] = t.x;
-                    in1[q] = t.y;
+                    in0[g][q] = t.x;
+                    in1[g][q] = t.y;
                 }
-                sweepEO< NQ, N1, false, false >(in0, o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1, o1, tIt);
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+            {
+                double o0[N1], o1[N1];
+                sweepEO< NQ, N1, false, false >(in0[g], o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1[g], o1, tIt);
 #pragma unroll
                 for (int k = 0; k < N1; ++k)
                 {
-                    double* dstl = sb + (i1 + N1 * (j1 + N1 * k)) * U + 2 * g;
-                    if constexpr (U % 2 == 0)
-                        *reinterpret_cast< double2* >(dstl) = make_double2(a.alpha * o0[k], a.alpha * o1[k]);
-                    else
-                    {
-                        dstl[0] = a.alpha * o0[k];
-                        if (2 * g + 1 < U)
-                            dstl[1] = a.alpha * o1[k];
-                    }
+                    const uint32_t slot = (k & 1) ? sw[k >> 1] >> 16 : sw[k >> 1] & 0xffffu;
+                    double*        dstl = sb + slot * U + 2 * g;
+                    *reinterpret_cast< double2* >(dstl) = make_double2(a.alpha * o0[k], a.alpha * o1[k]); // (U is even)
                 }
             }
         }
         stageFence();
-        // bufA is free now: stash this element's node ids there in local-node order for the scatter (LDS latency instead
-        // of a dependent global load per scatter round)
-        uint32_t* const idsL = reinterpret_cast< uint32_t* >(bufA);
-        if (on_nn && act)
+        L3K_STAMP(10);
+        // bufA is free now: stash this element's node ids there in slot order for the scatter (LDS latency instead of a
+        // dependent global load per scatter round)
+        if (w_nn)
         {
+            uint32_t* const idsL = reinterpret_cast< uint32_t* >(bufA);
+            const uint4     srow = slotRows[l];
+            const uint32_t  sw[4] = {srow.x, srow.y, srow.z, srow.w};
 #pragma unroll
             for (int k = 0; k < N1; ++k)
-                idsL[i1 + N1 * (j1 + N1 * k)] = ids_cur[k];
+                idsL[(k & 1) ? sw[k >> 1] >> 16 : sw[k >> 1] & 0xffffu] = ids_cur[k];
         }
         stageFence();
+        L3K_STAMP(11);
         loadIds(batch + stride, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
-        // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) with lanes running over (node, unknown) pairs,
-        // unknown fastest: a wave-instruction covers contiguous dofs, the dense shape the atomic units need
-        if (act)
+        // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) in SLOT order by all 64 lanes: slots [0, nsh) are the
+        // shell nodes in ascending-id order of a typical element -- one double per lane and round, so that an atomic
+        // wave-instruction covers runs of contiguous dofs with every 64-byte request full (the memory-side atomic units
+        // are a chip-wide request-rate limit: DESIGN.md 4.1) -- and slots [nsh, NN) the element's exclusive nodes: 16-byte
+        // stores of alpha*A*x + beta*y.  Without an exclusive range (fuse_beta == 0) every node takes the atomic path.
+        // (the scatter's per-lane constants are rebuilt here from an opaque copy of the lane id: as loop invariants they
+        // would be kept in registers across the sweeps, which have none to spare)
+        const int lane_s = opaqueCopy(lane);
+        const int steam_s = lane_s / SG, sl = lane_s - steam_s * SG;
+        if (steam_s < EW && (int64_t(batch) * EW + steam_s) < a.elem_count)
         {
-            const double*   sb      = reinterpret_cast< const double* >(bufB);
-            const bool flagged = flag_cur != 0;
-            // measured (profiles/r01_kbench_scatter_variants.log): two unknowns per lane and round halve the loop overhead
-            // and give 16-byte stores on exclusive nodes, but halve the density of the atomic wave-instructions; it wins
-            // where exclusive nodes are many (order >= 6: 36 % of an element's nodes), loses at order 4 (22 %)
-            if constexpr (P >= 6)
-            {
-                // two unknowns (16 bytes) per lane and round: half the address / branch overhead, 16-byte stores on
-                // exclusive nodes; consecutive lanes still cover consecutive dofs
-                const double2* sb2 = reinterpret_cast< const double2* >(sb);
-#pragma unroll 2
-                for (int t = l; t < NN * (U / 2); t += TEAM)
+            const double* const   sb      = lds + size_t(steam_s) * Cfg::TEAM_D + Cfg::BUF_D;
+            const uint32_t* const idsS    = reinterpret_cast< const uint32_t* >(lds + size_t(steam_s) * Cfg::TEAM_D);
+            const bool            flagged = (flag_cur & 2u) != 0;
+            // (SG is a multiple of U: a lane keeps its unknown and moves SG / U slots per round -- every LDS address below is
+            // one per-lane base plus a compile-time offset)
+            static_assert(SG % U == 0);
+            const int             sl_node = sl / U, sl_o = sl % U, sl_node2 = sl / (U / 2), sl_o2 = 2 * (sl % (U / 2));
+            const uint32_t* const ids1 = idsS + sl_node;
+            const double* const   sb1  = sb + sl;
+            const uint32_t* const ids2 = idsS + sl_node2;
+            const double2* const  sb2  = reinterpret_cast< const double2* >(sb) + sl;
+            // FLAGGED: the element touches a Dirichlet dof (those dofs are skipped / written as beta*y, :517-536).  Only the
+            // common variant (exclusive range present, no Dirichlet dof) is unrolled: without branches inside the rounds
+            // its LDS reads are issued ahead of the address arithmetic of earlier rounds
+            auto shellRound = [&]< int NSH_, bool FLAGGED >(int r) {
+                if ((r + 1) * SG > NSH_ * U && r * SG + sl >= NSH_ * U)
+                    return;
+                const int64_t node = ids1[r * (SG / U)];
+                const int64_t dof  = node * U + sl_o;
+                const double  val  = sb1[r * SG];
+                double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                if constexpr (FLAGGED)
+                    if (a.dirichlet[dof] != 0)
+                        return;
+                if (L3K_DBG(a) & (1 | 32 | 64)) // ablation: 1 / 64 = no memory operation, 32 = plain store
                 {
-                    const int     nl   = t / (U / 2);
-                    const int     o    = 2 * (t - nl * (U / 2));
-                    const int64_t node = idsL[nl];
-                    const int64_t dof  = node * U + o;
-                    const double2 val  = sb2[t];
-                    const bool    d0   = flagged && a.dirichlet[dof] != 0, d1 = flagged && a.dirichlet[dof + 1] != 0;
-                    double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                    if (L3K_DBG(a) & 1)
-                    {
-                        if (val.x == 1.2345e300)
-                            *dst = val.x;
-                    }
-                    else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
-                    {
-                        // touched by this element only: y = alpha*(A x) + beta*y written here, no atomic, and for beta = 0
-                        // no read either (these rows are skipped by the pre-scaling pass, l3k_mf_scale); Dirichlet dofs
-                        // contribute nothing (MatrixFreeSystem.hpp:517-536)
-                        double2 out = make_double2(d0 ? 0. : val.x, d1 ? 0. : val.y);
-                        if (a.beta != 0.)
-                        {
-                            const double2 old = *reinterpret_cast< const double2* >(dst);
-                            out.x += a.beta * old.x;
-                            out.y += a.beta * old.y;
-                        }
-                        *reinterpret_cast< double2* >(dst) = out;
-                    }
-                    else
-                    {
-                        if (L3K_DBG(a) & 96) // ablation: 32 = plain 16-byte store instead of the atomics, 64 = no memory operation
-                        {
-                            if ((L3K_DBG(a) & 32) || val.x == 1.2345e300)
-                                *reinterpret_cast< double2* >(dst) = val;
-                            continue;
-                        }
-                        if (!d0)
-                        {
-                            if (L3K_DBG(a) & 16)
-                                dst[0] += val.x;
-                            else
-                                unsafeAtomicAdd(dst, val.x);
-                        }
-                        if (!d1)
-                        {
-                            if (L3K_DBG(a) & 16)
-                                dst[1] += val.y;
-                            else
-                                unsafeAtomicAdd(dst + 1, val.y);
-                        }
-                    }
+                    if ((L3K_DBG(a) & 32) || val == 1.2345e300)
+                        *dst = val;
                 }
+                else if (L3K_DBG(a) & 16)
+                    *dst += val;
+                else
+                    unsafeAtomicAdd(dst, val);
+            };
+            auto exclRound = [&]< int NSH_, bool FLAGGED >(int r) {
+                if (NSH_ * (U / 2) + r * SG + sl >= NN * (U / 2))
+                    return;
+                const int64_t node = ids2[NSH_ + r * (SG / (U / 2))];
+                const int64_t dof  = node * U + sl_o2;
+                const double2 val  = sb2[NSH_ * (U / 2) + r * SG];
+                double*       dst  = a.y + dof; // (exclusive nodes are owned)
+                double2       out  = val;
+                if constexpr (FLAGGED)
+                {
+                    out.x = a.dirichlet[dof] != 0 ? 0. : val.x;
+                    out.y = a.dirichlet[dof + 1] != 0 ? 0. : val.y;
+                }
+                if (L3K_DBG(a) & 1)
+                {
+                    if (val.x == 1.2345e300)
+                        *dst = val.x;
+                    return;
+                }
+                if (a.beta != 0.)
+                {
+                    const double2 old = *reinterpret_cast< const double2* >(dst);
+                    out.x += a.beta * old.x;
+                    out.y += a.beta * old.y;
+                }
+                *reinterpret_cast< double2* >(dst) = out;
+            };
+            constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * (U / 2) + SG - 1) / SG;
+            if (a.fuse_beta && !flagged)
+            {
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    shellRound.template operator()< Cfg::NSH, false >(r);
+#pragma unroll
+                for (int r = 0; r < RX; ++r)
+                    exclRound.template operator()< Cfg::NSH, false >(r);
+            }
+            else if (a.fuse_beta)
+            {
+#pragma unroll 1
+                for (int r = 0; r < RS; ++r)
+                    shellRound.template operator()< Cfg::NSH, true >(r);
+#pragma unroll 1
+                for (int r = 0; r < RX; ++r)
+                    exclRound.template operator()< Cfg::NSH, true >(r);
+            }
+            else if (!flagged)
+            {
+#pragma unroll 1
+                for (int r = 0; r < (NN * U + SG - 1) / SG; ++r)
+                    shellRound.template operator()< NN, false >(r);
             }
             else
             {
-#pragma unroll 4
-                for (int t = l; t < NN * U; t += TEAM)
-                {
-                    const int     nl   = t / U;
-                    const int     o    = t - nl * U;
-                    const int64_t node = idsL[nl];
-                    const int64_t dof  = node * U + o;
-                    const bool    dir  = flagged && a.dirichlet[dof] != 0;
-                    const double  val  = sb[t];
-                    double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
-                    if (L3K_DBG(a) & 1)
-                    {
-                        if (val == 1.2345e300)
-                            *dst = val;
-                    }
-                    else if (a.fuse_beta && node >= a.exclusive_node_begin && node < a.exclusive_node_end)
-                        *dst = (dir ? 0. : val) + (a.beta == 0. ? 0. : a.beta * *dst);
-                    else if (!dir)
-                    {
-                        if (L3K_DBG(a) & 16)
-                            *dst += val;
-                        else
-                            unsafeAtomicAdd(dst, val);
-                    }
-                }
+#pragma unroll 1
+                for (int r = 0; r < (NN * U + SG - 1) / SG; ++r)
+                    shellRound.template operator()< NN, true >(r);
             }
         }
         stageFence(); // the buffers are rewritten by the next batch
+        L3K_STAMP(12);
 #pragma unroll
         for (int k = 0; k < N1; ++k)
             ids_cur[k] = ids_nxt[k];
         flag_cur = flag_nxt;
+        ++stamp_it;
     }
 }
 

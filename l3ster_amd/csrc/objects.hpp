@@ -97,6 +97,11 @@ struct l3k_mesh
     DevBuf< int64_t >   owned_dirichlet_rows;
     DevBuf< uint8_t >   elem_flags;
     int64_t             exclusive_begin = 0, exclusive_end = 0;
+    // scatter order of the single-wave kernel: slot_tab[lane * 8 + k] = scatter slot of local node lane + (p+1)^2 * k; slots
+    // [0, n_shell) are the element's non-internal nodes in ascending node-id order of a typical element (runs of contiguous
+    // rows in y), slots [n_shell, N) its internal nodes = exactly the nodes of [exclusive_begin, exclusive_end)
+    DevBuf< uint16_t >  slot_tab;
+    int                 n_shell = 0;
     int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
     int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
 };

@@ -33,9 +33,40 @@ def run_one(order, ne, steps, perturb):
     torch.cuda.synchronize()
     ms = np.array([a.elapsed_time(b) for a, b in zip(e0, e1)])
     dofs = part.n_global_nodes * U
+    if os.environ.get("L3K_STAMPS"):
+        stage_timeline()
     print(f"flags={os.environ.get('L3K_DEBUG_FLAGS', '0'):>3} p={order} ne={ne} elems={part.n_elems} dofs={dofs} "
           f"ms(min/med)={ms.min():.3f}/{np.median(ms):.3f}  DOF/s={dofs / np.median(ms) * 1e3:.3e}  "
           f"ns/elem={np.median(ms) * 1e6 / part.n_elems:.1f}", flush=True)
+
+
+STAGES = ["gather+S1(z interp)", "S2 (y interp)", "S3/S4 (x interp, d/dxi)", "S5 (d/deta)", "S6 (d/dzeta)", "QP stage",
+          "S8/S9 (C^T eta, zeta)", "combine + C^T xi + I^T x", "I^T y", "I^T z + staging", "ids to LDS", "scatter issue"]
+
+
+def stage_timeline():
+    """Cycle counters of workgroup 0 at its stage boundaries (last launch), L3K_ABLATION build with L3K_STAMPS=1."""
+    import ctypes as C
+    import numpy as np
+    from l3ster_amd import capi
+    lib = capi.load()
+    buf = np.zeros(256 * 16, dtype=np.int64)
+    fn = lib.l3k_debug_stamps
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_int64), C.c_int]
+    if fn(buf.ctypes.data_as(C.POINTER(C.c_int64)), buf.size) != 0:
+        print("no stamps (needs the ablation library and L3K_STAMPS=1)")
+        return
+    t = buf.reshape(256, 16)
+    n = int((t[:, 0] != 0).sum())
+    if n < 4:
+        print("stamps: too few iterations recorded")
+        return
+    t = t[1:n - 1]  # steady state
+    d = np.diff(t[:, :13], axis=1)
+    tot = t[1:, 0] - t[:-1, 0]
+    print(f"stage timeline of workgroup 0, {len(t)} elements, cycles per element: median total {np.median(tot):.0f}")
+    for name, col in zip(STAGES, d.T):
+        print(f"  {name:28s} median {np.median(col):8.0f}  mean {col.mean():8.0f}  ({100 * col.mean() / tot.mean():4.1f} %)")
 
 
 if __name__ == "__main__":
