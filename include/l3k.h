@@ -304,6 +304,17 @@ typedef struct
 } l3k_hostmesh_view;
 int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* out);
 
+/* ---- native results file (host only; post/NativeIO.hpp:15-60 save, :115-146 LoadedResults, :277-295 loadResultsImpl) --
+ * "L3STER results file\nv1.0\n// <comment>\n", size_t n_fields, size_t n_nodes_global, then n_fields arrays of
+ * n_nodes_global doubles indexed by global node id.  Every rank saves its owned slice [node_begin, node_begin + n_local)
+ * of each field (fields: host, [n_fields][ld]); exactly one rank passes write_header != 0 (the reference: rank 0).  No
+ * ordering between the ranks' calls is required.  Loading gathers field values by global node id (node_ids == NULL:
+ * the contiguous range starting at node_begin), as Loader::loadResults does with the saved partition's node ids.       */
+int l3k_results_save(const char* path, const char* comment, size_t n_fields, int64_t n_global_nodes, int64_t node_begin,
+                     int64_t n_local_nodes, const double* fields, size_t ld, int write_header);
+int l3k_results_info(const char* path, size_t* n_fields, size_t* n_nodes);
+int l3k_results_load(const char* path, size_t field, int64_t n, const int64_t* node_ids, int64_t node_begin, double* out);
+
 #ifdef __cplusplus
 }
 #endif

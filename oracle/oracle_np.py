@@ -235,3 +235,27 @@ def boundary_nodes(dim, p):
         if any(i in (0, n - 1) for i in bi):
             out.append(b)
     return np.array(out)
+
+
+# ---- native results file: restatement of post/NativeIO.hpp (writer :15-60, reader LoadedResults :115-146) -------------
+def results_file_bytes(fields, comment=""):
+    """The whole file for field-major values [n_fields][n_nodes_global]: header text, two size_t, the doubles."""
+    f = np.ascontiguousarray(fields, dtype=np.float64)
+    header = ("L3STER results file\nv1.0\n// %s\n" % comment.replace("\n", " ")).encode()  # :38-39
+    header += np.array([f.shape[0], f.shape[1]], dtype=np.uint64).tobytes()  # util::serialize(size_t) x2, :40-41
+    return header + f.tobytes()  # field i at header + 8 * n_nodes * i  (:50-52)
+
+
+def results_file_parse(data):
+    """LoadedResults: skip 3 lines (:120-121), read (n_fields, n_nodes) (:124), values(node, field) at
+    8 * (n_nodes * field + node) (:133-139).  Returns (comment, [n_fields][n_nodes])."""
+    pos = 0
+    lines = []
+    for _ in range(3):
+        nl = data.index(b"\n", pos)
+        lines.append(data[pos:nl])
+        pos = nl + 1
+    n_fields, n_nodes = (int(v) for v in np.frombuffer(data[pos:pos + 16], dtype=np.uint64))
+    vals = np.frombuffer(data[pos + 16:pos + 16 + 8 * n_fields * n_nodes], dtype=np.float64).reshape(n_fields, n_nodes)
+    assert lines[0] == b"L3STER results file" and lines[1] == b"v1.0" and lines[2].startswith(b"// ")
+    return lines[2][3:].decode(), vals
