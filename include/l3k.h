@@ -304,6 +304,15 @@ typedef struct
 } l3k_hostmesh_view;
 int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* out);
 
+/* ---- order elevation on the device (mesh::convertMeshToOrder, mesh/ConvertMeshToOrder.hpp:51-104, followed
+ * by the [non-internal | internal] renumbering of mesh/LocalMeshView.hpp:425-458) --------------------------------------
+ * conn: host, [n_elems][8] vertex ids of an order-1 hex mesh, local vertex v = i + 2j + 4k.  Writes elem_nodes (host,
+ * [n_elems][(order+1)^3], local node i + n(j + n k)) numbered [vertices | edge nodes | face nodes | element-internal
+ * nodes, contiguous per element]: ready for l3k_mesh_desc.elem_nodes of a single-rank mesh (n_owned_nodes = *n_nodes).
+ * Shared edges / faces are found by sorting their vertex keys on the device; every element is processed in parallel.    */
+int l3k_elevate_order(l3k_ctx* ctx, int64_t n_elems, const uint32_t* conn, int64_t n_vertices, int order, uint32_t* elem_nodes,
+                      int64_t* n_nodes, int64_t* n_noninternal);
+
 /* ---- native results file (host only; post/NativeIO.hpp:15-60 save, :115-146 LoadedResults, :277-295 loadResultsImpl) --
  * "L3STER results file\nv1.0\n// <comment>\n", size_t n_fields, size_t n_nodes_global, then n_fields arrays of
  * n_nodes_global doubles indexed by global node id.  Every rank saves its owned slice [node_begin, node_begin + n_local)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "l3k_cube_partition_create": (C.c_int, [c_int_p, C.c_int, c_int_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     "l3k_hostmesh_destroy": (C.c_int, [_vp]),
     "l3k_hostmesh_view_get": (C.c_int, [_vp, C.POINTER(HostMeshView)]),
+    "l3k_elevate_order": (C.c_int, [_vp, C.c_int64, c_uint32_p, C.c_int64, C.c_int, c_uint32_p, c_int64_p, c_int64_p]),
     "l3k_results_save": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int64, c_double_p, C.c_size_t,
                                    C.c_int]),
     "l3k_results_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -61,6 +61,14 @@ struct DevBuf
         if (ptr)
             (void)hipFree(ptr);
     }
+    int alloc(size_t count)
+    {
+        n = count;
+        if (count == 0)
+            return 0;
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ptr), count * sizeof(T)));
+        return 0;
+    }
     int upload(const T* host, size_t count, hipStream_t s)
     {
         n = count;

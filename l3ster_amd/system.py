@@ -218,6 +218,38 @@ class Context:
             self._h = None
 
 
+def elevate_order(ctx, conn, n_vertices, order):
+    """Order elevation of an order-1 hex mesh on the device (l3k_elevate_order; mesh::convertMeshToOrder +
+    LocalMeshView's numbering): conn [n_elems][8] vertex ids (local vertex i + 2j + 4k) -> (elem_nodes
+    [n_elems][(order+1)^3] uint32, n_nodes, n_noninternal)."""
+    lib = capi.load()
+    c = np.ascontiguousarray(conn, dtype=np.uint32).reshape(-1, 8)
+    out = np.empty((c.shape[0], (order + 1) ** 3), dtype=np.uint32)
+    nn, nni = C.c_int64(), C.c_int64()
+    capi.check(lib.l3k_elevate_order(ctx._h, c.shape[0], c.ctypes.data_as(capi.c_uint32_p), int(n_vertices), int(order),
+                                     out.ctypes.data_as(capi.c_uint32_p), C.byref(nn), C.byref(nni)))
+    return out, nn.value, nni.value
+
+
+class ElevatedHexMesh:
+    """A single-rank order-p hex mesh made from an unstructured order-1 one on the device: the mesh object DeviceMesh
+    and the operators take (same attributes as CubePartition; no ghosts, no neighbours)."""
+
+    def __init__(self, ctx, verts, conn, order):
+        verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        conn = np.ascontiguousarray(conn, dtype=np.uint32).reshape(-1, 8)
+        self.dim, self.order, self.rank, self.parts = 3, order, 0, (1, 1, 1)
+        self.elem_nodes, n_nodes, self.n_noninternal = elevate_order(ctx, conn, verts.shape[0], order)
+        self.elem_verts = verts[conn.astype(np.int64)]  # [n_elems][8][3]
+        self.n_elems = self.n_interior_elems = conn.shape[0]
+        self.n_owned_nodes, self.n_ghost_nodes = n_nodes, 0
+        self.global_node_base, self.n_global_nodes = 0, n_nodes
+        self.nbr_rank, self.send_nodes, self.ghost_ranges = [], [], []
+
+    n_local_nodes = CubePartition.n_local_nodes
+    node_coords = CubePartition.node_coords
+
+
 class DeviceMesh:
     def __init__(self, ctx, part, dofs_per_node, dirichlet=None):
         self.ctx, self.part, self.dofs_per_node = ctx, part, dofs_per_node

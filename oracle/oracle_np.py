@@ -259,3 +259,84 @@ def results_file_parse(data):
     vals = np.frombuffer(data[pos + 16:pos + 16 + 8 * n_fields * n_nodes], dtype=np.float64).reshape(n_fields, n_nodes)
     assert lines[0] == b"L3STER results file" and lines[1] == b"v1.0" and lines[2].startswith(b"// ")
     return lines[2][3:].decode(), vals
+
+
+# ---- order elevation of an order-1 hex mesh: restatement of the SPECIFICATION in l3ster_amd/csrc/api_mesh.hip -----------
+# (the reference's convertMeshToOrder, mesh/ConvertMeshToOrder.hpp:51-104, numbers by traversal order; what it and this
+# share -- and what tests/MeshTests.cpp:244-279 checks -- is the topology: one node per vertex, p-1 per edge, (p-1)^2 per
+# face, (p-1)^3 per element, ids contiguous)
+def _edge_verts(e):
+    d, q = e >> 2, e & 3
+    c0, c1 = q & 1, q >> 1
+    if d == 0:
+        va = 2 * c0 + 4 * c1
+        return va, va + 1
+    if d == 1:
+        va = c0 + 4 * c1
+        return va, va + 2
+    va = c0 + 2 * c1
+    return va, va + 4
+
+
+def _face_vert(f, s, t):
+    hi = f & 1
+    return [s + 2 * t + 4 * hi, s + 4 * t + 2 * hi, 2 * s + 4 * t + hi][f >> 1]
+
+
+def elevate_order(conn, n_vertices, p):
+    """conn [n_elems][8] (local vertex v = i + 2j + 4k) -> (elem_nodes [n_elems][(p+1)^3], n_nodes, n_noninternal)."""
+    conn = np.asarray(conn, dtype=np.int64).reshape(-1, 8)
+    ne, n1, m = conn.shape[0], p + 1, p - 1
+    ev = np.array([_edge_verts(e) for e in range(12)])
+    ekeys = np.sort(conn[:, ev], axis=2).reshape(-1, 2)  # (min, max) per (element, edge)
+    fv = np.array([[_face_vert(f, q & 1, q >> 1) for q in range(4)] for f in range(6)])
+    fkeys = np.sort(conn[:, fv], axis=2).reshape(-1, 4)
+    if ne:
+        _, edge_id = np.unique(ekeys, axis=0, return_inverse=True)  # lexicographic order of the unique keys
+        _, face_id = np.unique(fkeys, axis=0, return_inverse=True)
+        edge_id, face_id = edge_id.reshape(ne, 12), face_id.reshape(ne, 6)
+        n_edges, n_faces = int(edge_id.max()) + 1, int(face_id.max()) + 1
+    else:
+        edge_id, face_id, n_edges, n_faces = np.zeros((0, 12), int), np.zeros((0, 6), int), 0, 0
+    edge_base, face_base = n_vertices, n_vertices + n_edges * m
+    int_base = face_base + n_faces * m * m
+    out = np.empty((ne, n1 ** 3), dtype=np.int64)
+    for k in range(n1):
+        for j in range(n1):
+            for i in range(n1):
+                ln = i + n1 * (j + n1 * k)
+                bi, bj, bk = i in (0, p), j in (0, p), k in (0, p)
+                nb = bi + bj + bk
+                if nb == 3:
+                    out[:, ln] = conn[:, (1 if i else 0) + 2 * (1 if j else 0) + 4 * (1 if k else 0)]
+                elif nb == 2:
+                    if not bi:
+                        le, t = (1 if j else 0) + 2 * (1 if k else 0), i
+                    elif not bj:
+                        le, t = 4 + (1 if i else 0) + 2 * (1 if k else 0), j
+                    else:
+                        le, t = 8 + (1 if i else 0) + 2 * (1 if j else 0), k
+                    va, vb = _edge_verts(le)
+                    pos = np.where(conn[:, va] < conn[:, vb], t - 1, p - 1 - t)
+                    out[:, ln] = edge_base + edge_id[:, le] * m + pos
+                elif nb == 1:
+                    if bk:
+                        f, s, t = (1 if k else 0), i, j
+                    elif bj:
+                        f, s, t = 2 + (1 if j else 0), i, k
+                    else:
+                        f, s, t = 4 + (1 if i else 0), j, k
+                    corners = conn[:, [_face_vert(f, q & 1, q >> 1) for q in range(4)]]
+                    o = np.argmin(corners, axis=1)  # first minimum = the device loop's strict '<'
+                    os_, ot = o & 1, o >> 1
+                    rows = np.arange(ne)
+                    ns = corners[rows, (1 - os_) + 2 * ot]
+                    nt = corners[rows, os_ + 2 * (1 - ot)]
+                    ds = np.where(os_ == 1, p - s, s)
+                    dt = np.where(ot == 1, p - t, t)
+                    a = np.where(ns < nt, ds, dt)
+                    b = np.where(ns < nt, dt, ds)
+                    out[:, ln] = face_base + face_id[:, f] * m * m + (a - 1) + m * (b - 1)
+                else:
+                    out[:, ln] = int_base + np.arange(ne) * m ** 3 + (i - 1) + m * ((j - 1) + m * (k - 1))
+    return out, int_base + ne * m ** 3, int_base
