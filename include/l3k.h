@@ -145,7 +145,9 @@ int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t 
  * algsys/MatrixFreeSystem.hpp:1046-1111).  Ghost values live in separate [n_ghost_dofs][ncols] buffers exactly like
  * m_import_shared_buf / m_export_shared_buf (:1008-1009), accessed through BorderAccessor semantics
  * (algsys/ComputeValuesAtNodes.hpp:21-50): local dof < n_owned -> owned vector, else ghost buffer.
- *   which: 0 = interior elements, 1 = border elements, 2 = all. */
+ *   which: 0 = interior elements, 1 = border elements, 2 = all; 3 / 4 = first / second half of the interior elements
+ *   (the schedule import || first half, border, export || second half hides both exchanges; the reference overlaps
+ *   only the import, :1046-1086). */
 /* Y <- beta*Y (:1038) on the rows the element kernels ACCUMULATE into.  Rows of nodes that belong to exactly one element
  * (the element-internal nodes of the reference's numbering, mesh/LocalMeshView.hpp:425-458) are not touched here when
  * the operator covers all dofs of a node: l3k_mf_apply_elems WRITES alpha*A*x + beta*y there (no atomics, and for

@@ -219,8 +219,16 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
         a.elem_begin = 0;
         a.elem_count = m->n_elems;
         break;
+    case 3: // first / second half of the interior elements: one half overlaps the import, the other the export
+        a.elem_begin = 0;
+        a.elem_count = m->n_interior / 2;
+        break;
+    case 4:
+        a.elem_begin = m->n_interior / 2;
+        a.elem_count = m->n_interior - m->n_interior / 2;
+        break;
     default:
-        setError("which must be 0 (interior), 1 (border) or 2 (all)");
+        setError("which must be 0 (interior), 1 (border), 2 (all), 3 or 4 (first / second half of the interior)");
         return -1;
     }
     if (mf->kp.n_fields > 0 && !mf->fields)
@@ -808,7 +816,7 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         setError("leading dimension smaller than the number of owned dofs");
         return -1;
     }
-    if (m->n_ghost_nodes > 0 && which != 0 && (!d_xghost || !d_yghost))
+    if (m->n_ghost_nodes > 0 && (which == 1 || which == 2) && (!d_xghost || !d_yghost))
     {
         setError("mesh has ghost nodes: border elements need the ghost import/export buffers");
         return -1;
@@ -863,9 +871,11 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         }
     }
     // boundary equation kernels registered on this system act on the sides of the same element range
-    for (l3k_bnd* b : mf->boundary_terms)
-        if (int rc = bndApplyImpl(b, which, d_x, ldx, d_xghost, ldxg, d_y, ldy, d_yghost, ldyg, ncols, alpha))
-            return rc;
+    // (the halves of the interior: all sides of interior elements go with the first half)
+    if (which != 4)
+        for (l3k_bnd* b : mf->boundary_terms)
+            if (int rc = bndApplyImpl(b, which == 3 ? 0 : which, d_x, ldx, d_xghost, ldxg, d_y, ldy, d_yghost, ldyg, ncols, alpha))
+                return rc;
     return 0;
 }
 

@@ -92,7 +92,7 @@ class DistributedOperator:
         reqs = self.transport.post(sends, recvs)
         if events is not None:
             events[0].record()
-        be.apply_elems(0, X, None, Y, None, alpha, beta)  # interior: overlaps the exchange
+        be.apply_elems(3, X, None, Y, None, alpha, beta)  # first half of the interior: overlaps the import
         if events is not None:
             events[1].record()
         self.transport.wait(reqs)
@@ -111,7 +111,9 @@ class DistributedOperator:
             sends.append((nb, src))
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             recvs.append((nb, rbuf))
-        self.transport.wait(self.transport.post(sends, recvs))
+        reqs = self.transport.post(sends, recvs)
+        be.apply_elems(4, X, None, Y, None, alpha, beta)  # second half of the interior: overlaps the export
+        self.transport.wait(reqs)
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             be.unpack_add_rows(rbuf, idx, Y)
         be.dirichlet_rows(X, Y, alpha)

@@ -46,7 +46,8 @@ class OracleBackend:
         yg = YG[:, :ng] if YG is not None else torch.zeros((nc, ng), dtype=torch.float64)
         xl = np.asfortranarray(torch.cat([X, xg], dim=1).numpy().T)
         yl = np.asfortranarray(torch.cat([Y, yg], dim=1).numpy().T.copy())
-        e0, e1 = (0, self.part.n_interior_elems) if which == 0 else (self.part.n_interior_elems, self.part.n_elems)
+        ni = self.part.n_interior_elems
+        e0, e1 = {0: (0, ni), 1: (ni, self.part.n_elems), 2: (0, self.part.n_elems), 3: (0, ni // 2), 4: (ni // 2, ni)}[which]
         O.mf_apply(self.mesh, self.kid, xl, yl, alpha=alpha, kparams=self.kparams, e_begin=e0, e_end=e1, do_scale=False,
                    do_dirichlet_rows=False)
         Y.copy_(torch.as_tensor(yl[:self.n_owned].T.copy()))
