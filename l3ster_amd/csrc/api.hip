@@ -149,7 +149,7 @@ const KernelMeta* findKernel(int id)
 // stage timeline of the single-wave kernel (tools/kbench.py --stamps): 256 iterations x 16 cycle counters of workgroup 0
 namespace
 {
-constexpr int n_stamps = 256 * 16;
+constexpr int n_stamps = 256 * 16 + 2 * 4096; // + start / end clock of every workgroup (up to 4096)
 long long*    debugStamps()
 {
     static long long* buf = [] {
@@ -184,6 +184,13 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.exclusive_node_begin = m->exclusive_begin;
     a.exclusive_node_end   = m->exclusive_end;
     a.slot_tab             = m->slot_tab.ptr;
+    // dynamic batch distribution of the single-wave kernel (L3K_FAST_STATIC=1: the static deal)
+    static const bool static_deal = std::getenv("L3K_FAST_STATIC") != nullptr;
+    if (!static_deal && !mf->ctx->work_counters)
+    {
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&mf->ctx->work_counters), 8 * 128));
+    }
+    a.work_counters = static_deal ? nullptr : mf->ctx->work_counters;
     a.n_shell              = m->n_shell;
     a.tables          = mf->tables.ptr;
     a.tables_host     = mf->tables_host.data();

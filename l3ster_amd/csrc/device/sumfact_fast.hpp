@@ -261,7 +261,25 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     const int stride = by_xcd ? int(gridDim.x) >> 3 : int(gridDim.x);
     const int first  = by_xcd ? int(blockIdx.x & 7) * xcd_chunk : 0;
     const int last   = by_xcd ? (first + xcd_chunk < nb ? first + xcd_chunk : nb) : nb;
-    int       batch  = first + (by_xcd ? int(blockIdx.x >> 3) : int(blockIdx.x));
+    // Dynamic distribution (a.work_counters != nullptr): every wave draws its next batch from a counter of its XCD, one
+    // returning atomic per element, issued at the top of the element and consumed only after the quadrature stage (its
+    // latency, behind the previous element's atomics in the in-order memory queue, is never waited for).  With a static
+    // deal the waves of one launch finished between 56 % and 100 % of the kernel's duration (a wave alone on its SIMD is
+    // faster, boundary elements are slower, ...): profiles/r01_kbench_stage_timeline.log.  Batch = base + ticket * step:
+    // the XCD's contiguous chunk (by_xcd), or batches congruent to the XCD index modulo 8 (the static deal's mapping).
+    const bool      dyn      = a.work_counters != nullptr;
+    const bool      sharded  = by_xcd || (gridDim.x & 7u) == 0;
+    uint32_t* const counter  = a.work_counters + (sharded ? 32 * (blockIdx.x & 7u) : 0); // 128 bytes apart
+    const int       dyn_base = by_xcd ? first : (sharded ? int(blockIdx.x & 7u) : 0);
+    const int       dyn_step = by_xcd || !sharded ? 1 : 8;
+    auto            drawTicket = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (dyn && lane == 0)
+            t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    };
+    auto ticketBatch = [&](uint32_t t) { return dyn_base + int(__builtin_amdgcn_readfirstlane(t)) * dyn_step; };
+    int  batch       = dyn ? ticketBatch(drawTicket()) : first + (by_xcd ? int(blockIdx.x >> 3) : int(blockIdx.x));
     // ---- software pipeline state: node ids two batches ahead, x values one batch ahead
     uint32_t      ids_cur[N1], ids_nxt[N1];
     double        xn[N1][U];
@@ -341,8 +359,13 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     loadIds(batch, ids_cur, flag_cur);
 
     [[maybe_unused]] int stamp_it = 0;
-    for (; batch < last; batch += stride)
+#ifdef L3K_ABLATION
+    if (a.stamps != nullptr && blockIdx.x < 4096 && lane == 0)
+        a.stamps[256 * 16 + 2 * blockIdx.x] = __builtin_readcyclecounter();
+#endif
+    while (batch < last)
     {
+        const uint32_t ticket = drawTicket(); // the batch after this one
         L3K_STAMP(0);
         // this team has an element in this batch (always, with one element per wave: batch < last <= elem_count)
         const bool act = (int64_t(batch) * EW + team) < a.elem_count;
@@ -748,7 +771,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         }
         stageFence();
         L3K_STAMP(11);
-        loadIds(batch + stride, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
+        const int batch_next = dyn ? ticketBatch(ticket) : batch + stride;
+        loadIds(batch_next, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) in SLOT order by all 64 lanes: slots [0, nsh) are the
         // shell nodes in ascending-id order of a typical element -- one double per lane and round, so that an atomic
         // wave-instruction covers runs of contiguous dofs with every 64-byte request full (the memory-side atomic units
@@ -859,8 +883,13 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         for (int k = 0; k < N1; ++k)
             ids_cur[k] = ids_nxt[k];
         flag_cur = flag_nxt;
+        batch    = batch_next;
         ++stamp_it;
     }
+#ifdef L3K_ABLATION
+    if (a.stamps != nullptr && blockIdx.x < 4096 && lane == 0)
+        a.stamps[256 * 16 + 2 * blockIdx.x + 1] = __builtin_readcyclecounter();
+#endif
 }
 
 template < typename K, int P, int NQ >
@@ -928,6 +957,11 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     const int         xcd_chunk = ((P >= 6 || xcd_force) && xcd_env && grid % 8 == 0 && n_batches >= int64_t(grid) && n_batches < (int64_t(1) << 30))
                                       ? int((n_batches + 7) / 8)
                                       : 0;
+    if (a.work_counters && hipMemsetAsync(a.work_counters, 0, 8 * 128, stream) != hipSuccess)
+    {
+        setError("hipMemsetAsync(work counters) failed");
+        return -3;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)

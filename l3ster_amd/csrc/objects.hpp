@@ -88,10 +88,13 @@ struct l3k_ctx
     int         device;
     hipStream_t stream;
     double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
+    uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes)
     ~l3k_ctx()
     {
         if (red_ws)
             (void)hipFree(red_ws);
+        if (work_counters)
+            (void)hipFree(work_counters);
     }
 };
 struct l3k_mesh

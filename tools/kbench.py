@@ -50,13 +50,22 @@ def stage_timeline():
     import numpy as np
     from l3ster_amd import capi
     lib = capi.load()
-    buf = np.zeros(256 * 16, dtype=np.int64)
+    buf = np.zeros(256 * 16 + 2 * 4096, dtype=np.int64)
     fn = lib.l3k_debug_stamps
     fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_int64), C.c_int]
     if fn(buf.ctypes.data_as(C.POINTER(C.c_int64)), buf.size) != 0:
         print("no stamps (needs the ablation library and L3K_STAMPS=1)")
         return
-    t = buf.reshape(256, 16)
+    life = buf[256 * 16:].reshape(4096, 2)
+    life = life[(life[:, 0] != 0) & (life[:, 1] != 0)]
+    if len(life):
+        # (s_memtime is per XCD: compare workgroups of one XCD, i.e. every 8th)
+        for x in range(8):
+            lx = life[x::8]
+            t0, dur = lx[:, 0].min(), lx[:, 1] - lx[:, 0].min()
+            print(f"  XCD {x}: {len(lx)} workgroups, end time after the XCD's first start: min {dur.min()} median {int(np.median(dur))} "
+                  f"max {dur.max()} cycles; mean lifetime / max = {(lx[:, 1] - lx[:, 0]).mean() / dur.max():.2f}")
+    t = buf[:256 * 16].reshape(256, 16)
     n = int((t[:, 0] != 0).sum())
     if n < 4:
         print("stamps: too few iterations recorded")
