@@ -267,19 +267,34 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     // deal the waves of one launch finished between 56 % and 100 % of the kernel's duration (a wave alone on its SIMD is
     // faster, boundary elements are slower, ...): profiles/r01_kbench_stage_timeline.log.  Batch = base + ticket * step:
     // the XCD's contiguous chunk (by_xcd), or batches congruent to the XCD index modulo 8 (the static deal's mapping).
-    const bool      dyn      = a.work_counters != nullptr;
-    const bool      sharded  = by_xcd || (gridDim.x & 7u) == 0;
-    uint32_t* const counter  = a.work_counters + (sharded ? 32 * (blockIdx.x & 7u) : 0); // 128 bytes apart
-    const int       dyn_base = by_xcd ? first : (sharded ? int(blockIdx.x & 7u) : 0);
-    const int       dyn_step = by_xcd || !sharded ? 1 : 8;
-    auto            drawTicket = [&]() -> uint32_t {
+    // A wave whose XCD has run dry continues with the next XCD's counter (the chunks that hold the Dirichlet faces take
+    // ~7 % longer): at most 7 switches per wave, each with one exposed atomic round trip, at the very end of the launch.
+    const bool dyn     = a.work_counters != nullptr;
+    const bool sharded = by_xcd || (gridDim.x & 7u) == 0;
+    int        victim  = sharded ? int(blockIdx.x & 7u) : 0, switches = 0;
+    auto       vBase   = [&](int v) { return by_xcd ? v * xcd_chunk : v; };
+    auto       vLimit  = [&](int v) { return by_xcd ? (v * xcd_chunk + xcd_chunk < nb ? v * xcd_chunk + xcd_chunk : nb) : nb; };
+    const int  dyn_step = by_xcd || !sharded ? 1 : 8;
+    auto       drawTicket = [&]() -> uint32_t {
         uint32_t t = 0;
         if (dyn && lane == 0)
-            t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = __hip_atomic_fetch_add(a.work_counters + 32 * victim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // 128 B apart
         return t;
     };
-    auto ticketBatch = [&](uint32_t t) { return dyn_base + int(__builtin_amdgcn_readfirstlane(t)) * dyn_step; };
-    int  batch       = dyn ? ticketBatch(drawTicket()) : first + (by_xcd ? int(blockIdx.x >> 3) : int(blockIdx.x));
+    // batch of a ticket drawn from the current victim, or the end marker nb when every counter is exhausted
+    auto ticketBatch = [&](uint32_t t) {
+        int b = vBase(victim) + int(__builtin_amdgcn_readfirstlane(t)) * dyn_step;
+        while (b >= vLimit(victim))
+        {
+            if (!by_xcd || ++switches > 7) // (interleaved batches: every XCD has the same mix of elements, nothing to steal)
+                return nb;
+            victim = (victim + 1) & 7;
+            b      = vBase(victim) + int(__builtin_amdgcn_readfirstlane(drawTicket())) * dyn_step;
+        }
+        return b;
+    };
+    const int lim   = dyn ? nb : last; // loop bound: dynamic batches are valid below nb
+    int       batch = dyn ? ticketBatch(drawTicket()) : first + (by_xcd ? int(blockIdx.x >> 3) : int(blockIdx.x));
     // ---- software pipeline state: node ids two batches ahead, x values one batch ahead
     uint32_t      ids_cur[N1], ids_nxt[N1];
     double        xn[N1][U];
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     uint32_t      dm_nxt[N1];
     const int64_t n_owned_nodes = a.n_owned_dofs / U;
     auto          elemOf = [&](int b) { return a.elem_begin + int64_t(b) * EW + team; };
-    auto          valid  = [&](int b) { return (b < last) & on_nn & ((int64_t(b) * EW + team) < a.elem_count); };
+    auto          valid  = [&](int b) { return (b < lim) & on_nn & ((int64_t(b) * EW + team) < a.elem_count); };
     const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
     auto       loadIds    = [&](int batch, uint32_t (&ids)[N1], uint32_t& flag) {
         // "element touches a Dirichlet dof", fetched with the ids, one element ahead of its use: bit 0 for the element this
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         // (per-lane addresses rebuilt from an opaque copy of the lane id: see the scatter)
         const int lane_o = opaqueCopy(lane), steam = lane_o / SG;
         uint32_t  fg = 0, fs = 0;
-        if (have_flags && batch < last)
+        if (have_flags && batch < lim)
         {
             if (steam < EW && (int64_t(batch) * EW + steam) < a.elem_count)
                 fs = a.elem_flags[a.elem_begin + int64_t(batch) * EW + steam];
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     if (a.stamps != nullptr && blockIdx.x < 4096 && lane == 0)
         a.stamps[256 * 16 + 2 * blockIdx.x] = __builtin_readcyclecounter();
 #endif
-    while (batch < last)
+    while (batch < lim)
     {
         const uint32_t ticket = drawTicket(); // the batch after this one
         L3K_STAMP(0);

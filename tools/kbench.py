@@ -58,6 +58,8 @@ def stage_timeline():
         return
     life = buf[256 * 16:].reshape(4096, 2)
     life = life[(life[:, 0] != 0) & (life[:, 1] != 0)]
+    if os.environ.get("L3K_STAMPS_DUMP"):
+        np.save(os.environ["L3K_STAMPS_DUMP"], buf)
     if len(life):
         # (s_memtime is per XCD: compare workgroups of one XCD, i.e. every 8th)
         for x in range(8):
