@@ -61,14 +61,17 @@ def stage_timeline():
     if os.environ.get("L3K_STAMPS_DUMP"):
         np.save(os.environ["L3K_STAMPS_DUMP"], buf)
     if len(life):
-        # (s_memtime is per XCD: compare workgroups of one XCD, i.e. every 8th)
+        # (the clock is per CU / shader engine: only end - start of one workgroup is meaningful, not differences between them)
+        d = life[:, 1] - life[:, 0]
+        print(f"workgroup lifetimes (cycles), {len(d)} workgroups: min {d.min()} p5 {int(np.percentile(d, 5))} median "
+              f"{int(np.median(d))} p95 {int(np.percentile(d, 95))} max {d.max()}; mean / max = {d.mean() / d.max():.3f}")
         for x in range(8):
-            lx = life[x::8]
-            t0, dur = lx[:, 0].min(), lx[:, 1] - lx[:, 0].min()
-            print(f"  XCD {x}: {len(lx)} workgroups, end time after the XCD's first start: min {dur.min()} median {int(np.median(dur))} "
-                  f"max {dur.max()} cycles; mean lifetime / max = {(lx[:, 1] - lx[:, 0]).mean() / dur.max():.2f}")
+            dx = d[x::8]
+            print(f"  XCD {x}: min {dx.min()} median {int(np.median(dx))} max {dx.max()}  mean / max = {dx.mean() / dx.max():.3f}")
     t = buf[:256 * 16].reshape(256, 16)
-    n = int((t[:, 0] != 0).sum())
+    n = 1  # (the buffer is not cleared between launches: the last launch's iterations are the increasing prefix)
+    while n < 256 and t[n, 0] > t[n - 1, 0]:
+        n += 1
     if n < 4:
         print("stamps: too few iterations recorded")
         return
