@@ -915,9 +915,9 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         return 0;
     // Small launches are latency-bound: one element takes ~23 us through a single wave here, ~15 us through the 6-wave
     // workgroup of the generic kernel; below ~3 elements per CU the generic kernel wins (profiles/r01_kbench_small_meshes.log:
-    // order 6, 216 elements 16 vs 23 us, crossover at ~1000 elements).  L3K_GENERIC_BELOW overrides the threshold.
+    // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements).  L3K_GENERIC_BELOW overrides.
     const char* const gb_env        = std::getenv("L3K_GENERIC_BELOW"); // (read per launch: the tests switch it)
-    const long        generic_below = gb_env ? std::atol(gb_env) : 768L;
+    const long        generic_below = gb_env ? std::atol(gb_env) : 1500L;
     constexpr bool generic_fits = applyLdsBytes< K, P, NQ, 1 >() <= lds_limit_bytes;
     if (!a.dense || (generic_fits && a.elem_count < generic_below)) // (non-dense dof layouts: generic kernel only)
         return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);

@@ -9,7 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# The product routes launches of fewer than 768 elements to the generic LDS kernel (lower latency on small meshes); the
+# The product routes launches of fewer than 1500 elements to the generic LDS kernel (lower latency on small meshes); the
 # parity tests run on small meshes and must exercise the one-wave-per-element kernel the benchmark uses, so the threshold
 # is 0 here.  tests/test_gpu_edge_cases.py::test_small_launch_routing covers the default routing.
 os.environ.setdefault("L3K_GENERIC_BELOW", "0")
