@@ -221,7 +221,11 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     // with fewer derivative groups than groups, buffer B is too small for the y / x interpolation of all groups: those two
     // sweeps then run in place in buffer A (a lane reads its whole pencil before it writes it; pencils are disjoint)
     constexpr bool INPLACE = DG < NG;
-    auto          at = [](int c, int b, int a_) { return a_ * PS + b * M + c; };
+    // LDS position of point (c, b, a_) = (x, y, z index), in 16-byte units.  With the lanes running over two of the three
+    // indices (first one fastest) the unit index modulo 16 must be distinct within 16 consecutive lanes: strides (1, 7) and
+    // (49 = 1, 7) are, (1, 49 = 1) is not -- one of the three pencil orientations is always 3-way bank-conflicted.  y
+    // gets the plane stride so that it is the z-oriented accesses (84 per element) and not the y-oriented ones (112).
+    auto          at = [](int c, int b, int a_) { return b * PS + a_ * M + c; };
 
     extern __shared__ double lds[];
     const int                lane = threadIdx.x;
