@@ -326,3 +326,30 @@ def test_operator_properties_at_full_size(ctx, ne, p):
     rows = rows[mask[rows] == 0]
     assert len(rows) > 1000
     assert rel_err(Ax.cpu().numpy()[0, rows], ys[rows, 0]) < 1e-11
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_one_gpu():
+    """The RCCL point-to-point transport of the partitioned apply, as far as one GPU allows (see the script's docstring)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_exchange.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL self exchange ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_partitioned_apply_through_rccl_on_one_gpu():
+    """8 logical ranks' partitioned apply with every message carried by RCCL (self send / receive on one GPU): see the
+    script's docstring."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_partitioned_apply.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL partitioned apply ok" in r.stdout, r.stdout + r.stderr
