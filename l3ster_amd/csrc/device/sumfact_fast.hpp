@@ -209,7 +209,10 @@ struct FastCfg
     static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : L3K_FAST_MIN_WAVES;
 };
 
-template < typename K, int P, int NQ >
+// SPLIT: ghost rows live in buffers of their own (a.xg / a.yg, the reference's import / export buffers): every node needs
+// an owned-or-ghost select.  SPLIT = false (no ghost buffers in this launch -- one rank, or interior elements -- or ghost
+// rows directly behind the owned rows): one base pointer, ~150 instructions per element less.
+template < typename K, int P, int NQ, bool SPLIT >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         for (int k = 0; k < N1; ++k)
         {
             const int64_t node = ids[k];
-            const double* p    = node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
+            const double* p    = !SPLIT || node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
 #pragma unroll
             for (int hh = 0; hh < U / 2; ++hh)
             {
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 const int64_t node = ids1[r * (SG / U)];
                 const int64_t dof  = node * U + sl_o;
                 const double  val  = sb1[r * SG];
-                double*       dst  = node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                double*       dst  = !SPLIT || node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
                 if constexpr (FLAGGED)
                     if (a.dirichlet[dof] != 0)
                         return;
@@ -928,14 +931,17 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     K kern{};
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
-    auto        kernel   = sumfactFastKernel< K, P, NQ >;
+    const bool  split    = !((a.xg == nullptr || a.xg == a.x + a.n_owned_dofs) && (a.yg == nullptr || a.yg == a.y + a.n_owned_dofs));
+    auto        kernel   = split ? sumfactFastKernel< K, P, NQ, true > : sumfactFastKernel< K, P, NQ, false >;
     static int  n_cus    = 0;
     static int  waves_cu = 0;
     static bool attr_set = false;
     if (!attr_set)
     {
-        if (hipFuncSetAttribute(reinterpret_cast< const void* >(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(Cfg::lds)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true >),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false >),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess)
         {
             setError("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", Cfg::lds);
             return -3;
