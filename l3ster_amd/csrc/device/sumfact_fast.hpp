@@ -398,6 +398,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
+        // one masked region for everything up to the scatter: the lanes without a pencil (helpers of the scatter) skip it
+        if (w_all)
+        {
         loadX(w_nn, ids_cur, (flag_cur & 1u) != 0);
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
         double u0[N1][2 * NG];
@@ -791,7 +794,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             for (int k = 0; k < N1; ++k)
                 idsL[(k & 1) ? sw[k >> 1] >> 16 : sw[k >> 1] & 0xffffu] = ids_cur[k];
         }
-        stageFence();
+        } // if (w_all)
+        stageFence(); // (every lane: the scatter below reads what the pencil lanes staged)
         L3K_STAMP(11);
         const int batch_next = dyn ? ticketBatch(ticket) : batch + stride;
         loadIds(batch_next, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
