@@ -207,6 +207,9 @@ struct FastCfg
     static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
     // (three waves per SIMD for the small-LDS shapes was tried: 168 registers, spills, order 4 5.1 -> 7.5 ns per element)
     static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : L3K_FAST_MIN_WAVES;
+    // field groups whose LDS reads are issued together in the LDS -> LDS stages (2 * N1 doubles of registers per extra group).
+    // (order 4 at three waves per SIMD, 168 registers, was tried again with read_block = 1: still 34 spilled registers.)
+    static constexpr int read_block   = NG;
 };
 
 // SPLIT: ghost rows live in buffers of their own (a.xg / a.yg, the reference's import / export buffers): every node needs
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
     constexpr int HN = (N1 + 1) / 2, HQ = (NQ + 1) / 2;
+    constexpr int GB = Cfg::read_block; // field groups whose LDS reads are batched (register cost: 2 * N1 doubles per extra group)
     // with fewer derivative groups than groups, buffer B is too small for the y / x interpolation of all groups: those two
     // sweeps then run in place in buffer A (a lane reads its whole pencil before it writes it; pencils are disjoint)
     constexpr bool INPLACE = DG < NG;
@@ -460,25 +464,30 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             double tI[2 * HN * HQ];
             loadTable(tI, eoI + opaqueZero());
-            double        in0[NG][N1], in1[NG][N1];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int gb = 0; gb < NG; gb += GB)
+            {
+            double in0[GB][N1], in1[GB][N1];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < NG; ++g)
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
                 {
                     const double2 t = ldg(bufA, g, at(iq, j, kq));
-                    in0[g][j] = t.x;
-                    in1[g][j] = t.y;
+                    in0[g - gb][j] = t.x;
+                    in1[g - gb][j] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = gb; g < gb + GB && g < NG; ++g)
             {
                 double o0[NQ], o1[NQ];
-                sweepEO< N1, NQ, false, false >(in0[g], o0, tI);
-                sweepEO< N1, NQ, false, false >(in1[g], o1, tI);
+                sweepEO< N1, NQ, false, false >(in0[g - gb], o0, tI);
+                sweepEO< N1, NQ, false, false >(in1[g - gb], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(INPLACE ? bufA : bufB, g, at(iq, q, kq), o0[q], o1[q]);
+            }
             }
         }
         stageFence();
@@ -489,22 +498,26 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             double tI[2 * HN * HQ];
             loadTable(tI, eoI + opaqueZero());
-            double        in0[NG][N1], in1[NG][N1];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int gb = 0; gb < NG; gb += GB)
+            {
+            double in0[GB][N1], in1[GB][N1];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < NG; ++g)
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
                 {
                     const double2 t = ldg(INPLACE ? bufA : bufB, g, at(i, qa, qb));
-                    in0[g][i] = t.x;
-                    in1[g][i] = t.y;
+                    in0[g - gb][i] = t.x;
+                    in1[g - gb][i] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = gb; g < gb + GB && g < NG; ++g)
             {
                 double o0[NQ], o1[NQ];
-                sweepEO< N1, NQ, false, false >(in0[g], o0, tI);
-                sweepEO< N1, NQ, false, false >(in1[g], o1, tI);
+                sweepEO< N1, NQ, false, false >(in0[g - gb], o0, tI);
+                sweepEO< N1, NQ, false, false >(in1[g - gb], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
@@ -512,6 +525,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     v[q][2 * g + 1] = o1[q];
                     stg(bufA, g, at(q, qa, qb), o0[q], o1[q]);
                 }
+            }
             }
             double tC[2 * HQ * HQ];
             loadTable(tC, eoC + opaqueZero());
@@ -535,25 +549,30 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             double tC[2 * HQ * HQ];
             loadTable(tC, eoC + opaqueZero());
-            double in0[DG][NQ], in1[DG][NQ];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < DG; ++g)
+            for (int gb = 0; gb < DG; gb += GB)
+            {
+            double in0[GB][NQ], in1[GB][NQ];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < DG; ++g)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(qa, q, qb));
-                    in0[g][q] = t.x;
-                    in1[g][q] = t.y;
+                    in0[g - gb][q] = t.x;
+                    in1[g - gb][q] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < DG; ++g)
+            for (int g = gb; g < gb + GB && g < DG; ++g)
             {
                 double o0[NQ], o1[NQ];
-                sweepEO< NQ, NQ, true, false >(in0[g], o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1[g], o1, tC);
+                sweepEO< NQ, NQ, true, false >(in0[g - gb], o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1[g - gb], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
+            }
             }
         }
         stageFence();
@@ -563,25 +582,30 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             double tC[2 * HQ * HQ];
             loadTable(tC, eoC + opaqueZero());
-            double in0[DG][NQ], in1[DG][NQ];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < DG; ++g)
+            for (int gb = 0; gb < DG; gb += GB)
+            {
+            double in0[GB][NQ], in1[GB][NQ];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < DG; ++g)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(qa, qb, q));
-                    in0[g][q] = t.x;
-                    in1[g][q] = t.y;
+                    in0[g - gb][q] = t.x;
+                    in1[g - gb][q] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < DG; ++g)
+            for (int g = gb; g < gb + GB && g < DG; ++g)
             {
                 double o0[NQ], o1[NQ];
-                sweepEO< NQ, NQ, true, false >(in0[g], o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1[g], o1, tC);
+                sweepEO< NQ, NQ, true, false >(in0[g - gb], o0, tC);
+                sweepEO< NQ, NQ, true, false >(in1[g - gb], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
+            }
             }
         }
         stageFence();
@@ -725,25 +749,30 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             double tIt[2 * HQ * HN];
             loadTable(tIt, eoIt + opaqueZero());
-            double in0[UG][NQ], in1[UG][NQ];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < UG; ++g)
+            for (int gb = 0; gb < UG; gb += GB)
+            {
+            double in0[GB][NQ], in1[GB][NQ];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < UG; ++g)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufB, g, at(iq, q, kq));
-                    in0[g][q] = t.x;
-                    in1[g][q] = t.y;
+                    in0[g - gb][q] = t.x;
+                    in1[g - gb][q] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < UG; ++g)
+            for (int g = gb; g < gb + GB && g < UG; ++g)
             {
                 double o0[N1], o1[N1];
-                sweepEO< NQ, N1, false, false >(in0[g], o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1[g], o1, tIt);
+                sweepEO< NQ, N1, false, false >(in0[g - gb], o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1[g - gb], o1, tIt);
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
                     stg(bufA, g, at(iq, j, kq), o0[j], o1[j]);
+            }
             }
         }
         stageFence();
@@ -756,22 +785,26 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             double*       sb  = reinterpret_cast< double* >(bufB);
             const uint4   srow = slotRows[l]; // scatter slots of this lane's N1 nodes
             const uint32_t sw[4] = {srow.x, srow.y, srow.z, srow.w};
-            double in0[UG][NQ], in1[UG][NQ];
+            // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
 #pragma unroll
-            for (int g = 0; g < UG; ++g)
+            for (int gb = 0; gb < UG; gb += GB)
+            {
+            double in0[GB][NQ], in1[GB][NQ];
+#pragma unroll
+            for (int g = gb; g < gb + GB && g < UG; ++g)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufA, g, at(i1, j1, q));
-                    in0[g][q] = t.x;
-                    in1[g][q] = t.y;
+                    in0[g - gb][q] = t.x;
+                    in1[g - gb][q] = t.y;
                 }
 #pragma unroll
-            for (int g = 0; g < UG; ++g)
+            for (int g = gb; g < gb + GB && g < UG; ++g)
             {
                 double o0[N1], o1[N1];
-                sweepEO< NQ, N1, false, false >(in0[g], o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1[g], o1, tIt);
+                sweepEO< NQ, N1, false, false >(in0[g - gb], o0, tIt);
+                sweepEO< NQ, N1, false, false >(in1[g - gb], o1, tIt);
 #pragma unroll
                 for (int k = 0; k < N1; ++k)
                 {
@@ -779,6 +812,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     double*        dstl = sb + slot * U + 2 * g;
                     *reinterpret_cast< double2* >(dstl) = make_double2(a.alpha * o0[k], a.alpha * o1[k]); // (U is even)
                 }
+            }
             }
         }
         stageFence();
