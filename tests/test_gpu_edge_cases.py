@@ -153,3 +153,32 @@ def test_small_launch_routing(S, ctx, monkeypatch):
         out[name] = Y.cpu().numpy()
         assert helpers.rel_err(out[name].T, want) < 1e-12, name
     assert not np.array_equal(out["generic"], out["fast"])  # different kernels: different rounding
+
+
+@pytest.mark.parametrize("p", [2, 4, 6])
+def test_ghost_rows_behind_the_owned_rows(S, ctx, p):
+    """The element kernel comes in two variants: with an owned-or-ghost select per node (ghost rows in buffers of their
+    own, the reference's import / export buffers) and without (no ghost buffers, or ghost rows directly behind the owned
+    rows).  A rank with ghosts, all elements: both layouts must give the same result, and static batch distribution the
+    same as dynamic."""
+    U = 4
+    part = S.CubePartition((4, 4, 2), p, parts=(2, 2, 1), rank=3, perturb=0.1)
+    assert part.n_ghost_nodes > 0
+    mesh = S.DeviceMesh(ctx, part, U, part.dirichlet_mask(U))
+    mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [0.7, 1.0])
+    n_owned, n_ghost = part.n_owned_nodes * U, part.n_ghost_nodes * U
+    x = torch.as_tensor(part.synthetic_vector(U), device="cuda")  # (1, n_local_dofs): ghost values included
+    # separate ghost buffers
+    X, XG = x[:, :n_owned].clone(), x[:, n_owned:].clone()
+    Y = torch.zeros((1, n_owned), dtype=torch.float64, device="cuda")
+    YG = torch.zeros((1, n_ghost), dtype=torch.float64, device="cuda")
+    mf.apply_elems(2, X, XG, Y, YG, 1.5, 0.0)
+    # one allocation: ghost rows directly behind the owned rows
+    xc = x.clone()
+    yc = torch.zeros_like(xc)
+    mf.apply_elems(2, xc[:, :n_owned], xc[:, n_owned:], yc[:, :n_owned], yc[:, n_owned:], 1.5, 0.0)
+    torch.cuda.synchronize()
+    scale = float(Y.abs().max())
+    assert float((yc[:, :n_owned] - Y).abs().max()) < 1e-12 * scale
+    assert float((yc[:, n_owned:] - YG).abs().max()) < 1e-12 * scale
+    assert float(YG.abs().max()) > 0.0
