@@ -182,3 +182,14 @@ def test_ghost_rows_behind_the_owned_rows(S, ctx, p):
     assert float((yc[:, :n_owned] - Y).abs().max()) < 1e-12 * scale
     assert float((yc[:, n_owned:] - YG).abs().max()) < 1e-12 * scale
     assert float(YG.abs().max()) > 0.0
+
+
+def test_static_deal_fallback():
+    """L3K_FAST_STATIC=1 (static deal of the batches instead of the per-XCD counters) still agrees with the oracle."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "static_deal_check.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=dict(os.environ, L3K_FAST_STATIC="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "static deal ok" in r.stdout, r.stdout + r.stderr
