@@ -223,6 +223,27 @@ def main():
                                                      "unit": "TFLOP/s", "frac": rate * kd * nd * (nd + 1) / 1e12 / 78.6,
                                                      "flops": "symmetric half, 2*K*N*(N+1)/2 per element"}}
             del amf, amesh, apart
+            # BASELINE.json configs[1]: the same apply at order 4 on the same 64^3 mesh (outside the timed region)
+            p4 = 4
+            part4 = system.CubePartition(args.ne, p4, perturb=0.1)
+            mf4 = system.MatrixFreeSystem(system.DeviceMesh(ctx, part4, U, part4.dirichlet_mask(U)), kid, [1.0, 1.0])
+            X4 = system.synthetic_vector_torch(part4.node_grid_id[:part4.n_owned_nodes], U, dev)
+            Y4 = torch.empty_like(X4)
+            for _ in range(args.warmup):
+                mf4.apply(X4, Y4, 1.0, 0.0)
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
+            for _ in range(args.steps):
+                mf4.apply(X4, Y4, 1.0, 0.0)
+            b1.record()
+            torch.cuda.synchronize()
+            ms4 = b0.elapsed_time(b1) / args.steps
+            dofs4 = part4.n_global_nodes * U
+            result["order4_apply"] = {"workload": f"Diffusion3D matrix-free apply, hex mesh {args.ne}^3, order 4, {dofs4} dofs "
+                                                  "(BASELINE.json configs[1])",
+                                      "value": dofs4 / (ms4 * 1e-3), "unit": "DOF/s", "ms_per_step": ms4,
+                                      "roofline_frac_hbm": dofs4 / (ms4 * 1e-3) * algorithmic_bytes_per_dof(p4, U) / 1e9 / HBM_PEAK_GBS}
+            del mf4, X4, Y4, part4
         if world == 1 and op is None:
             if not args.no_cpu_baseline:
                 base, (spart, smask, sx, sy) = cpu_baseline(p, U)
