@@ -108,6 +108,37 @@ def test_restatement_topology_on_unstructured_and_rotated_meshes(p):
     check_topology(verts, rc, en_r, n_r, p)
 
 
+def scrambled_mesh(seed, p):
+    """A random subset of the gmsh cube's hexes with randomly rotated local frames and randomly relabelled vertices (the
+    canonical edge / face frames follow the vertex ids, so relabelling moves every orientation decision)."""
+    rng = np.random.default_rng(seed)
+    verts, conn, _ = gmsh_cube()
+    keep = rng.random(conn.shape[0]) < 0.4
+    conn = rotate_elements(conn[keep], seed)
+    relabel = rng.permutation(verts.shape[0])
+    new_verts = np.empty_like(verts)
+    new_verts[relabel] = verts
+    return new_verts, relabel[conn.astype(np.int64)].astype(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_restatement_topology_on_scrambled_meshes(seed):
+    p = 2 + seed % 4
+    verts, conn = scrambled_mesh(seed, p)
+    en, n_nodes, n_nonint = ONP.elevate_order(conn, verts.shape[0], p)
+    # vertices no element of the subset touches keep their ids but carry no element node: check the used ids only
+    used = np.unique(en)
+    assert used.max() == n_nodes - 1
+    loc = node_locations(verts, conn, en, p).reshape(-1, 3)
+    ids = en.reshape(-1)
+    lo = np.full((n_nodes, 3), np.inf)
+    hi = np.full((n_nodes, 3), -np.inf)
+    np.minimum.at(lo, ids, loc)
+    np.maximum.at(hi, ids, loc)
+    assert np.max((hi - lo)[used]) < 1e-12
+    assert np.unique(np.round(0.5 * (lo[used] + hi[used]), 9), axis=0).shape[0] == used.size
+
+
 # ---------------------------------------------------------------------------------------------------------- device
 @pytest.fixture(scope="module")
 def ctx():
@@ -177,3 +208,14 @@ def test_apply_on_elevated_mesh_matches_structured_generator(ctx, p, rotate):
     assert np.array_equal(np.sort(idx), np.arange(idx.size))
     err = np.linalg.norm(y_e - y_c[idx]) / np.linalg.norm(y_c)
     assert err < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_device_elevation_on_scrambled_meshes(ctx, seed):
+    p = 2 + seed % 4
+    verts, conn = scrambled_mesh(seed, p)
+    en, n_nodes, n_nonint = system.elevate_order(ctx, conn, verts.shape[0], p)
+    en_o, n_o, nn_o = ONP.elevate_order(conn, verts.shape[0], p)
+    assert (n_nodes, n_nonint) == (n_o, nn_o)
+    assert np.array_equal(en.astype(np.int64), en_o)
