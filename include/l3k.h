@@ -262,6 +262,11 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
                   l3k_cg_result* result);
 int l3k_cg_init(l3k_ctx* ctx, double* d_r, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s);
 int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t n, double* d_s);
+/* One rank, one column: y <- A x and s[1] <- <x, A x> in one pass (what the PCG needs of an apply followed by
+ * l3k_cg_dot_pap).  On the single-wave route of domain kernels the element kernel accumulates x^T A x = sum_q w detJ |B_q x|^2
+ * at the quadrature points (the Dirichlet rows, identity rows of the operator, add x_d^2): no pass over x and y afterwards.
+ * Otherwise (small meshes, attached boundary terms, other dof layouts) it is the apply followed by the dot product.     */
+int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s);
 int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
                      int64_t n, double* d_s);
 int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s);

@@ -191,6 +191,8 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
         L3K_HIP(hipMalloc(reinterpret_cast< void** >(&mf->ctx->work_counters), 8 * 128));
     }
     a.work_counters = static_deal ? nullptr : mf->ctx->work_counters;
+    a.energy        = ncols == 1 ? mf->energy_target : nullptr;
+    a.energy_done   = &mf->energy_done;
     a.n_shell              = m->n_shell;
     a.tables          = mf->tables.ptr;
     a.tables_host     = mf->tables_host.data();
@@ -899,6 +901,55 @@ int l3k_mf_dirichlet_rows(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y
     hipLaunchKernelGGL(dirichletRowsKernel, dim3(gridFor(int64_t(rows.n))), dim3(256), 0, mf->ctx->stream, rows.ptr,
                        int64_t(rows.n), d_x, ldx, d_y, ldy, ncols, alpha);
     L3K_HIP(hipGetLastError());
+    return 0;
+}
+
+// s[1] += sum over the owned Dirichlet rows of x_d^2 (their share of x^T A x: those rows of the operator are the identity)
+__global__ void dirichletEnergyKernel(const int64_t* __restrict__ rows, int64_t n, const double* __restrict__ x, double* __restrict__ s1)
+{
+    __shared__ double sh[256];
+    double            acc = 0.;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
+        acc += x[rows[i]] * x[rows[i]];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1)
+    {
+        if (int(threadIdx.x) < w)
+            sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && sh[0] != 0.)
+        unsafeAtomicAdd(s1, sh[0]);
+}
+
+int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s)
+{
+    if (!mf || !d_x || !d_y || !d_s)
+    {
+        setError("l3k_mf_apply_energy: null argument");
+        return -1;
+    }
+    const size_t n = size_t(mf->mesh->nOwnedDofs());
+    // the element kernel accumulates x^T A x only on its single-wave route and only for domain kernels
+    L3K_HIP(hipMemsetAsync(d_s + 1, 0, sizeof(double), mf->ctx->stream));
+    mf->energy_target = mf->boundary_terms.empty() ? d_s + 1 : nullptr;
+    mf->energy_done   = 0;
+    const int rc      = l3k_mf_apply(mf, d_x, n, d_y, n, 1, 1., 0.);
+    const bool fused  = mf->energy_target != nullptr && mf->energy_done != 0;
+    mf->energy_target = nullptr;
+    if (rc)
+        return rc;
+    if (!fused)
+        return l3k_cg_dot_pap(mf->ctx, d_x, d_y, int64_t(n), d_s); // (overwrites s[1])
+    const auto& rows = mf->mesh->owned_dirichlet_rows;
+    if (rows.n > 0)
+    {
+        const int64_t nr = int64_t(rows.n);
+        hipLaunchKernelGGL(dirichletEnergyKernel, dim3(unsigned(std::min< int64_t >((nr + 255) / 256, 1024))), dim3(256), 0,
+                           mf->ctx->stream, rows.ptr, nr, d_x, d_s + 1);
+        L3K_HIP(hipGetLastError());
+    }
     return 0;
 }
 

@@ -255,9 +255,7 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
     const int every = o.check_every > 0 ? o.check_every : 1;
     while (res > o.tol && it < o.max_iters)
     {
-        if (int rc = l3k_mf_apply(mf, p, size_t(n), ap, size_t(n), 1, 1., 0.))
-            return rc;
-        if (int rc = l3k_cg_dot_pap(ctx, p, ap, n, s))
+        if (int rc = l3k_mf_apply_energy(mf, p, ap, s)) // ap = A p, s[1] = <p, A p>
             return rc;
         if (int rc = l3k_cg_update_xr(ctx, d_x, r, p, ap, d_minv, n, s))
             return rc;

@@ -70,6 +70,8 @@ struct ElemArgs
     int64_t         elem_begin, elem_count;
     double          alpha, beta, time;
     int             fuse_beta; // rows of exclusive nodes are written as alpha*A*x + beta*y by the element kernel
+    double*         energy; // single-wave kernel: if set, x^T A x of the launch's elements is ADDED here (one atomic per wave)
+    int*            energy_done; // HOST flag: set to 1 by the launcher that ran the energy-accumulating kernel variant
     uint32_t*       work_counters; // single-wave kernel: 8 batch counters, 128 bytes apart, zeroed by the launcher (or nullptr: static deal)
     const uint16_t* slot_tab;  // single-wave kernel: [ (p+1)^2 ][8] scatter slots of a lane's local nodes (objects.hpp:l3k_mesh)
     int             n_shell;   // slots [0, n_shell) are scattered with atomics, [n_shell, N) are exclusive nodes (plain stores)

@@ -143,7 +143,8 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
 // The quadrature-point stage (evalAtHexQPs, algsys/SumFactorization.hpp:707-753) for one point.
 // v[op], dv[d][op]: values / REFERENCE derivatives of the operands (op = u + U*r) and, after them, the F fields.
 // On return r0[op], rd[d][op] hold A0^T t and D_d^T t.  RHS_MODE: t = wgt * (f - B x) (rhs with Dirichlet lifting).
-template < typename K, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
+// ENERGY: *energy += sum_e wgt * (B x)_e^2, this point's share of x^T A x.
+template < typename K, int R, bool RHS_MODE, int RT = R, int C0 = 0, bool ENERGY = false >
 __device__ __forceinline__ void qpStage(const K&      kern,
                                         const double (*G)[3],
                                         double        xi,
@@ -152,7 +153,8 @@ __device__ __forceinline__ void qpStage(const K&      kern,
                                         const double* v,
                                         const double (*dv)[K::params.n_unknowns * R + K::params.n_fields],
                                         double*       r0,
-                                        double (*rd)[K::params.n_unknowns * R])
+                                        double (*rd)[K::params.n_unknowns * R],
+                                        double*       energy = nullptr)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations, F = params.n_fields, OPS = U * R;
@@ -199,6 +201,8 @@ __device__ __forceinline__ void qpStage(const K&      kern,
                 acc += res.operators[0](e, u) * v[r * U + u] + Dm[0][e][u] * dv[0][r * U + u] +
                        Dm[1][e][u] * dv[1][r * U + u] + Dm[2][e][u] * dv[2][r * U + u];
             t[e] = RHS_MODE ? wgt * (res.rhs(e, C0 + r) - acc) : wgt * acc;
+            if constexpr (ENERGY)
+                *energy += acc * t[e];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)

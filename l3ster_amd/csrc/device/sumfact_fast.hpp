@@ -196,7 +196,7 @@ struct FastCfg
     static constexpr int    DF       = kernelUsesFieldDers< K >() ? NF : U; // fields with derivatives
     static constexpr int    BUF_D    = 2 * NG * OS;                         // buffer A (doubles)
     static constexpr int    BUFB_D   = 2 * DG * OS;                         // buffer B: derivative groups only
-    static constexpr int    TEAM_D   = BUF_D + BUFB_D + 24;
+    static constexpr int    TEAM_D   = BUF_D + BUFB_D + 24 + 2; // buffers, 8 vertices, energy accumulator (+ pad)
     static constexpr int    SLOT_B   = 16 * N1 * N1; // scatter-slot table of the mesh: [N1*N1 lanes][8] uint16, one copy per wave
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D + SLOT_B;
     static constexpr int    SG       = (64 / EW) / U * U; // lanes that scatter one element (the team's lanes + helpers): a multiple of U
@@ -215,7 +215,9 @@ struct FastCfg
 // SPLIT: ghost rows live in buffers of their own (a.xg / a.yg, the reference's import / export buffers): every node needs
 // an owned-or-ghost select.  SPLIT = false (no ghost buffers in this launch -- one rank, or interior elements -- or ghost
 // rows directly behind the owned rows): one base pointer, ~150 instructions per element less.
-template < typename K, int P, int NQ, bool SPLIT >
+// ENERGY: the kernel also accumulates x^T A x = sum_q wgt |B x|^2 of its elements into *a.energy (for <p, A p> of the PCG:
+// saves the separate dot-product pass over two vectors).
+template < typename K, int P, int NQ, bool SPLIT, bool ENERGY >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -380,6 +382,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     uint4* const slotRows = reinterpret_cast< uint4* >(lds + size_t(EW) * Cfg::TEAM_D);
     if (lane < N1 * N1)
         slotRows[lane] = reinterpret_cast< const uint4* >(a.slot_tab)[lane];
+    if constexpr (ENERGY)
+        if (worker && l == 0)
+            vs[24] = 0.;
     stageFence();
     uint32_t flag_cur, flag_nxt = 0;
     loadIds(batch, ids_cur, flag_cur);
@@ -613,6 +618,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
         if (w_qq)
         {
+            [[maybe_unused]] double en = 0.; // ENERGY: this pencil's share of x^T A x
             const double wyz = opaqueCopy(wyz_l); // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers)
             double       G[6][3];
             hexPencilGeom(vs, eta_l, zeta_l, G);
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     else // the kernel declared that it never reads the derivatives of the external fields
                         dv[0][o] = dv[1][o] = dv[2][o] = 0.;
                 }
-                qpStage< K, 1, false >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd);
+                qpStage< K, 1, false, 1, 0, ENERGY >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -655,6 +661,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     stg(bufA, g, at(q, qa, qb), rd[2][2 * g], 2 * g + 1 < U ? rd[2][2 * g + 1] : 0.);
                 }
             }
+            if constexpr (ENERGY) // LDS atomic add of every pencil's share into the team's accumulator
+                atomicAdd(vs + 24, en);
         }
         stageFence();
         L3K_STAMP(6);
@@ -946,6 +954,12 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         batch    = batch_next;
         ++stamp_it;
     }
+    if constexpr (ENERGY)
+    {
+        stageFence();
+        if (worker && l == 0 && vs[24] != 0.)
+            unsafeAtomicAdd(a.energy, vs[24]); // one global atomic per team and launch
+    }
 #ifdef L3K_ABLATION
     if (a.stamps != nullptr && blockIdx.x < 4096 && lane == 0)
         a.stamps[256 * 16 + 2 * blockIdx.x + 1] = __builtin_readcyclecounter();
@@ -970,16 +984,21 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
     const bool  split    = !((a.xg == nullptr || a.xg == a.x + a.n_owned_dofs) && (a.yg == nullptr || a.yg == a.y + a.n_owned_dofs));
-    auto        kernel   = split ? sumfactFastKernel< K, P, NQ, true > : sumfactFastKernel< K, P, NQ, false >;
+    auto        kernel   = a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
+                                    : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
     static int  n_cus    = 0;
     static int  waves_cu = 0;
     static bool attr_set = false;
     if (!attr_set)
     {
-        if (hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true >),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false >),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess)
+        const void* const variants[4] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
+                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
+                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
+                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >)};
+        bool ok = true;
+        for (const void* f : variants)
+            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;
+        if (!ok)
         {
             setError("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", Cfg::lds);
             return -3;
@@ -1026,6 +1045,8 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         return -3;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
+    if (a.energy && a.energy_done)
+        *a.energy_done = 1;
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
     {

@@ -132,6 +132,8 @@ struct l3k_mf
     size_t              ldf    = 0;
     double              time   = 0.;
     bool                dense = false, fuse = false;
+    double*             energy_target = nullptr; // l3k_mf_apply_energy: where the element kernel adds x^T A x (device)
+    int                 energy_done   = 0;       // ... and whether the launch did (else the caller falls back to a dot product)
     double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
     size_t              ws_doubles = 0;
     ~l3k_mf()

@@ -472,6 +472,12 @@ class MatrixFreeSystem:
         return Y
 
     # split-phase pieces (used by DistributedOperator)
+    def apply_energy(self, X, Y, S):
+        """Y <- A X (one column) and S[1] <- <X, A X> in one pass (l3k_mf_apply_energy): S is the PCG's device scalar
+        block (8 doubles)."""
+        check(capi.load().l3k_mf_apply_energy(self._h, _ptr(X), _ptr(Y), _ptr(S)))
+        return Y
+
     def scale(self, Y, beta):
         nc, ldy = self._cols(Y)
         check(capi.load().l3k_mf_scale(self._h, _ptr(Y), ldy, nc, beta))

@@ -122,3 +122,29 @@ def test_native_pcg_matches_torch_pcg():
     x3 = torch.zeros_like(diag)
     r3 = solve.pcg_distributed(Op(), ctx, rhs[0], x3, minv, tol=1e-10, residual_scaling="rhs")
     assert abs(r3.num_iters - r2.num_iters) <= 1 and (x3 - x2).norm().item() < 1e-8 * x2.norm().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,ne,fast", [(6, 4, True), (4, 5, True), (2, 6, True), (6, 3, False)])
+def test_apply_energy_equals_dot_product(p, ne, fast, monkeypatch):
+    """l3k_mf_apply_energy: y = A x and <x, A x> from the quadrature stage of the element kernel (fast = single-wave route)
+    or from the fallback dot product (small mesh on the generic route): both equal the explicit dot product."""
+    import torch
+    from l3ster_amd import system
+    monkeypatch.setenv("L3K_GENERIC_BELOW", "0" if fast else "1000000")
+    U = 4
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), system.KERNEL_DIFFUSION3D, [0.7, 1.0])
+    X = torch.as_tensor(part.synthetic_vector(U), device="cuda")  # non-zero on the Dirichlet rows too
+    Y = torch.full_like(X, 3.0)
+    S = torch.full((8,), 7.0, dtype=torch.float64, device="cuda")
+    mf.apply_energy(X, Y, S)
+    Yr = torch.zeros_like(X)
+    mf.apply(X, Yr)
+    torch.cuda.synchronize()
+    want = float((X * Yr).sum())
+    assert float((Y - Yr).abs().max()) <= 1e-12 * float(Yr.abs().max())
+    assert abs(float(S[1]) - want) <= 1e-12 * abs(want)
+    assert float(S[0]) == 7.0 and float(S[2]) == 7.0  # only slot 1 is written
