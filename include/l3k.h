@@ -267,6 +267,12 @@ int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t 
  * at the quadrature points (the Dirichlet rows, identity rows of the operator, add x_d^2): no pass over x and y afterwards.
  * Otherwise (small meshes, attached boundary terms, other dof layouts) it is the apply followed by the dot product.     */
 int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s);
+/* The same for the split-phase (partitioned) apply: l3k_mf_energy_begin zeroes s[1] and arms the accumulation for the
+ * l3k_mf_apply_elems calls that follow; l3k_mf_energy_end adds the owned Dirichlet rows' share, disarms, and reports in
+ * *fused whether every element launch in between accumulated (if not, s[1] is incomplete: take l3k_cg_dot_pap instead).
+ * s[1] then holds this rank's share of <x, A x>; the all-reduce over the ranks is the caller's, as for the other scalars. */
+int l3k_mf_energy_begin(l3k_mf* mf, double* d_s);
+int l3k_mf_energy_end(l3k_mf* mf, const double* d_x, int* fused);
 int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
                      int64_t n, double* d_s);
 int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s);

@@ -819,6 +819,8 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     l3k::dev::ElemArgs a;
     if (int rc = fillArgs(mf, which, ncols, a))
         return rc;
+    if (a.energy && a.elem_count > 0)
+        ++mf->energy_expected;
     const l3k_mesh* m = mf->mesh;
     if (ldx < size_t(m->nOwnedDofs()) || ldy < size_t(m->nOwnedDofs()))
     {
@@ -923,6 +925,40 @@ __global__ void dirichletEnergyKernel(const int64_t* __restrict__ rows, int64_t 
         unsafeAtomicAdd(s1, sh[0]);
 }
 
+int l3k_mf_energy_begin(l3k_mf* mf, double* d_s)
+{
+    if (!mf || !d_s)
+    {
+        setError("l3k_mf_energy_begin: null argument");
+        return -1;
+    }
+    L3K_HIP(hipMemsetAsync(d_s + 1, 0, sizeof(double), mf->ctx->stream));
+    // the element kernel accumulates x^T A x only on its single-wave route and only for domain kernels
+    mf->energy_target   = mf->boundary_terms.empty() ? d_s + 1 : nullptr;
+    mf->energy_done     = 0;
+    mf->energy_expected = 0;
+    return 0;
+}
+int l3k_mf_energy_end(l3k_mf* mf, const double* d_x, int* fused)
+{
+    if (!mf || !d_x || !fused)
+    {
+        setError("l3k_mf_energy_end: null argument");
+        return -1;
+    }
+    double* const s1  = mf->energy_target;
+    *fused            = s1 != nullptr && mf->energy_done == mf->energy_expected;
+    mf->energy_target = nullptr;
+    const auto& rows  = mf->mesh->owned_dirichlet_rows;
+    if (*fused && rows.n > 0)
+    {
+        const int64_t nr = int64_t(rows.n);
+        hipLaunchKernelGGL(dirichletEnergyKernel, dim3(unsigned(std::min< int64_t >((nr + 255) / 256, 1024))), dim3(256), 0,
+                           mf->ctx->stream, rows.ptr, nr, d_x, s1);
+        L3K_HIP(hipGetLastError());
+    }
+    return 0;
+}
 int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s)
 {
     if (!mf || !d_x || !d_y || !d_s)
@@ -931,26 +967,15 @@ int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s)
         return -1;
     }
     const size_t n = size_t(mf->mesh->nOwnedDofs());
-    // the element kernel accumulates x^T A x only on its single-wave route and only for domain kernels
-    L3K_HIP(hipMemsetAsync(d_s + 1, 0, sizeof(double), mf->ctx->stream));
-    mf->energy_target = mf->boundary_terms.empty() ? d_s + 1 : nullptr;
-    mf->energy_done   = 0;
-    const int rc      = l3k_mf_apply(mf, d_x, n, d_y, n, 1, 1., 0.);
-    const bool fused  = mf->energy_target != nullptr && mf->energy_done != 0;
-    mf->energy_target = nullptr;
+    if (int rc = l3k_mf_energy_begin(mf, d_s))
+        return rc;
+    const int rc = l3k_mf_apply(mf, d_x, n, d_y, n, 1, 1., 0.);
+    int       fused = 0;
+    if (int rc2 = l3k_mf_energy_end(mf, d_x, &fused))
+        return rc2;
     if (rc)
         return rc;
-    if (!fused)
-        return l3k_cg_dot_pap(mf->ctx, d_x, d_y, int64_t(n), d_s); // (overwrites s[1])
-    const auto& rows = mf->mesh->owned_dirichlet_rows;
-    if (rows.n > 0)
-    {
-        const int64_t nr = int64_t(rows.n);
-        hipLaunchKernelGGL(dirichletEnergyKernel, dim3(unsigned(std::min< int64_t >((nr + 255) / 256, 1024))), dim3(256), 0,
-                           mf->ctx->stream, rows.ptr, nr, d_x, d_s + 1);
-        L3K_HIP(hipGetLastError());
-    }
-    return 0;
+    return fused ? 0 : l3k_cg_dot_pap(mf->ctx, d_x, d_y, int64_t(n), d_s); // (the dot product overwrites s[1])
 }
 
 int l3k_mf_apply(l3k_mf* mf, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha, double beta)

@@ -1046,7 +1046,7 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
     if (a.energy && a.energy_done)
-        *a.energy_done = 1;
+        ++*a.energy_done;
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
     {

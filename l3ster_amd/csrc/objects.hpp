@@ -133,7 +133,8 @@ struct l3k_mf
     double              time   = 0.;
     bool                dense = false, fuse = false;
     double*             energy_target = nullptr; // l3k_mf_apply_energy: where the element kernel adds x^T A x (device)
-    int                 energy_done   = 0;       // ... and whether the launch did (else the caller falls back to a dot product)
+    int                 energy_done   = 0;       // ... how many element launches did (the launcher counts)
+    int                 energy_expected = 0;     // ... of how many non-empty ones: equal = fused, else the caller takes a dot product
     double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
     size_t              ws_doubles = 0;
     ~l3k_mf()

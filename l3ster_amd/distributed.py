@@ -74,10 +74,16 @@ class DistributedOperator:
                 stage=[mk(e - b) for _, b, e in self.plan.owners])
         return self._bufs[key]
 
-    def apply(self, X, Y, alpha=1.0, beta=0.0, events=None):
-        """events: optional (start, stop) torch.cuda.Event pair recorded around the interior-element launch (bench.py)"""
+    def apply(self, X, Y, alpha=1.0, beta=0.0, events=None, energy=None):
+        """events: optional (start, stop) torch.cuda.Event pair recorded around the interior-element launch (bench.py).
+        energy: the PCG's device scalar block S; if the backend can, S[1] receives this rank's share of <X, A X> from the
+        element kernels (alpha = 1, beta = 0, one column) and self.energy_fused says whether it did."""
         be, plan = self.backend, self.plan
         nc = X.shape[0]
+        self.energy_fused = False
+        arm = energy is not None and nc == 1 and alpha == 1.0 and beta == 0.0 and hasattr(be, "energy_begin")
+        if arm:
+            be.energy_begin(energy)
         b = self._buffers(nc, X)
         xg, yg = b["xg"], b["yg"]
         be.scale(Y, beta)
@@ -117,6 +123,8 @@ class DistributedOperator:
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             be.unpack_add_rows(rbuf, idx, Y)
         be.dirichlet_rows(X, Y, alpha)
+        if arm:
+            self.energy_fused = be.energy_end(X)
         return Y
 
     def import_ghosts(self, V):

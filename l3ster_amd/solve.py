@@ -107,6 +107,8 @@ def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residu
     s = torch.zeros(8, dtype=torch.float64, device=b.device)
     r, p, ap = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    import inspect
+    fuse_energy = "energy" in inspect.signature(op.apply).parameters
 
     def reduce(view):
         if allreduce is not None:  # pluggable (the threaded multi-rank emulation of the tests)
@@ -125,8 +127,20 @@ def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residu
     scale = {"none": 1.0, "initial": rr0 if rr0 > 0 else 1.0, "rhs": max(bb.item() ** 0.5, 1e-300)}[residual_scaling]
     res, it = rr0 / scale, 0
     while res > tol and it < max_iters:
-        op.apply(p[None, :], ap[None, :])
-        capi.check(lib.l3k_cg_dot_pap(ctx._h, vp(p), vp(ap), n, vp(s)))
+        if fuse_energy:  # <p, A p> from the element kernels' quadrature stage where they can (l3k_mf_energy_*)
+            op.apply(p[None, :], ap[None, :], energy=s)
+            if it == 0:
+                # element-wise shares (fused) and row-wise shares (dot product) of <p, A p> do not add up across ranks:
+                # every rank must take the same route.  Decided once -- it depends on the launch sizes only.
+                n_not = torch.tensor([0.0 if op.energy_fused else 1.0], dtype=torch.float64, device=b.device)
+                reduce(n_not)
+                fuse_energy = n_not.item() == 0.0
+            elif not op.energy_fused:
+                raise RuntimeError("the element kernels stopped accumulating <p, A p>")
+        else:
+            op.apply(p[None, :], ap[None, :])
+        if not fuse_energy:
+            capi.check(lib.l3k_cg_dot_pap(ctx._h, vp(p), vp(ap), n, vp(s)))
         reduce(s[1:2])
         capi.check(lib.l3k_cg_update_xr(ctx._h, vp(x), vp(r), vp(p), vp(ap), vp(minv), n, vp(s)))
         reduce(s[2:4])

@@ -478,6 +478,15 @@ class MatrixFreeSystem:
         check(capi.load().l3k_mf_apply_energy(self._h, _ptr(X), _ptr(Y), _ptr(S)))
         return Y
 
+    def energy_begin(self, S):
+        check(capi.load().l3k_mf_energy_begin(self._h, _ptr(S)))
+
+    def energy_end(self, X):
+        """True if S[1] now holds this rank's share of <X, A X> (else take the dot product)."""
+        fused = C.c_int(0)
+        check(capi.load().l3k_mf_energy_end(self._h, _ptr(X), C.byref(fused)))
+        return bool(fused.value)
+
     def scale(self, Y, beta):
         nc, ldy = self._cols(Y)
         check(capi.load().l3k_mf_scale(self._h, _ptr(Y), ldy, nc, beta))

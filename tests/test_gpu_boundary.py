@@ -265,11 +265,14 @@ class ThreadAllReduce:
         return allreduce
 
 
-@pytest.mark.parametrize("ne,parts", [((4, 4, 2), (2, 2, 1)), ((4, 4, 4), (2, 2, 2))])
-def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
+@pytest.mark.parametrize("ne,parts,adiabatic", [((4, 4, 2), (2, 2, 1), True), ((4, 4, 4), (2, 2, 2), True),
+                                                  ((4, 4, 4), (2, 2, 2), False), ((6, 3, 3), (2, 1, 1), False)])
+def test_partitioned_solve_end_to_end(S, ctx, ne, parts, adiabatic):
     """The whole partitioned flow on emulated ranks: Dirichlet values from a boundary residual kernel (contributions
     exported to the owners and averaged), diag / rhs with import of the Dirichlet values and export of the ghost rows,
-    boundary term, native PCG pieces with all-reduced scalars -- reproduces T = x, q = (1, 0, 0) on a distorted mesh."""
+    boundary term, native PCG pieces with all-reduced scalars -- reproduces T = x, q = (1, 0, 0) on a distorted mesh.
+    adiabatic = False: T = x prescribed on all six sides instead of the adiabatic boundary term on four of them; without
+    boundary terms the element kernels deliver <p, A p> themselves (l3k_mf_energy_*), which every rank must report."""
     import queue
     import threading
     from l3ster_amd import solve
@@ -285,11 +288,13 @@ def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
         try:
             torch.cuda.set_device(0)
             part = S.CubePartition(ne, p, parts, rank, perturb=0.1)
-            mask = part.dirichlet_mask(U, sides=(4, 5))
+            dir_sides = (4, 5) if adiabatic else tuple(range(6))
+            mask = part.dirichlet_mask(U, sides=dir_sides)
             c = S.Context(0, torch.cuda.current_stream().cuda_stream)
             mesh = S.DeviceMesh(c, part, U, mask)
             mf = S.MatrixFreeSystem(mesh, S.KERNEL_DIFFUSION3D, [1.0, 0.0])
-            mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, *part.boundary_sides([0, 1, 2, 3])))
+            if adiabatic:
+                mf.attach_boundary(S.BoundaryTerm(mesh, S.KERNEL_ADIABATIC3D, *part.boundary_sides([0, 1, 2, 3])))
             op = DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes))
             n_owned = part.n_owned_nodes * U
             # setDirichletBCValues on a partition: local sums / counts, ghost rows to their owners, average
@@ -298,7 +303,7 @@ def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
             lib = capi.load()
             nl = part.n_local_nodes * U
             sc = torch.zeros((2, nl), dtype=torch.float64, device="cuda")
-            fe, fs = part.boundary_sides([4, 5])
+            fe, fs = part.boundary_sides(list(dir_sides))
             di = (C.c_int * 1)(0)
             capi.check(lib.l3k_values_at_nodes(c._h, mesh._h, S.RESIDUAL_COORDX3D, None, 0, None, 0, 0.0, fe.size,
                                                fe.ctypes.data_as(capi.c_int64_p), fs.ctypes.data_as(capi.c_uint8_p), di,
@@ -316,7 +321,7 @@ def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
             coords = part.node_coords()[:part.n_owned_nodes]
             sol = x.view(-1, U).cpu().numpy()
             out[rank] = (res.num_iters, np.abs(sol[:, 0] - coords[:, 0]).max(), np.abs(sol[:, 1] - 1.0).max(),
-                         np.abs(sol[:, 2:]).max())
+                         np.abs(sol[:, 2:]).max(), op.energy_fused)
         except Exception as exc:  # pragma: no cover
             errors.append((rank, repr(exc)))
             try:
@@ -334,3 +339,4 @@ def test_partitioned_solve_end_to_end(S, ctx, ne, parts):
     assert len(iters) == 1  # every rank saw the same reduced scalars
     for r in range(world):
         assert out[r][1] < 1e-9 and out[r][2] < 1e-8 and out[r][3] < 1e-8, (r, out[r])
+        assert out[r][4] == (not adiabatic), (r, out[r])
