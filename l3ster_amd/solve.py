@@ -95,7 +95,7 @@ def pcg(system, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="n
 
 
 def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="none", group=None,
-                    throw_on_fail=True, allreduce=None):
+                    throw_on_fail=True, allreduce=None, check_every=1):
     """The same iteration for a partitioned system: `op.apply(X, Y)` is a DistributedOperator over this rank's owned
     rows; the fused l3k_cg_* kernels keep the scalars in a device block that is all-reduced between them (two small
     all-reduces per iteration, as Belos does)."""
@@ -144,9 +144,10 @@ def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residu
         reduce(s[1:2])
         capi.check(lib.l3k_cg_update_xr(ctx._h, vp(x), vp(r), vp(p), vp(ap), vp(minv), n, vp(s)))
         reduce(s[2:4])
-        res = s[3].item() ** 0.5 / scale
         capi.check(lib.l3k_cg_update_p(ctx._h, vp(p), vp(r), vp(minv), n, vp(s)))
         it += 1
+        if it % check_every == 0 or it == max_iters:  # (the only host synchronisation of the iteration)
+            res = s[3].item() ** 0.5 / scale
     converged = res <= tol
     if throw_on_fail and not converged:
         raise RuntimeError("Solver failed to converge")

@@ -60,7 +60,8 @@ if use_dist:
     dist.barrier()
 t0 = time.perf_counter()
 if use_dist:  # fused l3k_cg_* kernels + neighbour exchange in the apply + 2 scalar all-reduces per iteration
-    res = solve.pcg_distributed(op, ctx, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000)
+    res = solve.pcg_distributed(op, ctx, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000,
+                                check_every=a.check_every)
 else:  # l3k_pcg_solve: apply + fused vector kernels + reductions behind the C ABI (one 32-byte readback per check)
     res = solve.pcg(mf, rhs[0], x, minv, tol=a.tol, residual_scaling="rhs", max_iters=5000, check_every=a.check_every)
 torch.cuda.synchronize()
