@@ -819,7 +819,7 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     l3k::dev::ElemArgs a;
     if (int rc = fillArgs(mf, which, ncols, a))
         return rc;
-    if (a.energy && a.elem_count > 0)
+    if (a.elem_count > 0 && (a.energy || mf->energy_target)) // (armed but ncols > 1: a.energy is null, never "fused")
         ++mf->energy_expected;
     const l3k_mesh* m = mf->mesh;
     if (ldx < size_t(m->nOwnedDofs()) || ldy < size_t(m->nOwnedDofs()))
