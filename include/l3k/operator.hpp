@@ -243,10 +243,39 @@ public:
             throw std::runtime_error{"Solver failed to converge"};
         return res;
     }
+    // Y <- A X and d_s[1] <- <X, A X> in one pass (what a CG iteration needs of the operator; d_s: 8 device doubles)
+    void applyEnergy(const double* d_x, double* d_y, double* d_s) const { check(l3k_mf_apply_energy(m_mf, d_x, d_y, d_s)); }
     l3k_mf* get() const { return m_mf; }
 
 private:
     l3k_mf* m_mf{};
 };
+
+// convertMeshToOrder< order >(mesh_o1) for one rank's hexahedra (mesh/ConvertMeshToOrder.hpp:51-104), on the device:
+// conn = [n_elems][8] vertex ids, local vertex i + 2j + 4k.  Returns the element-node table [n_elems][(order+1)^3] in the
+// numbering [vertices | edge nodes | face nodes | element-internal nodes]; n_nodes receives the node count.
+inline std::vector< uint32_t > elevateOrder(Context& ctx, std::span< const uint32_t > conn, int64_t n_vertices, int order,
+                                            int64_t& n_nodes)
+{
+    const int64_t           n_elems = int64_t(conn.size() / 8), N = int64_t(order + 1) * (order + 1) * (order + 1);
+    std::vector< uint32_t > elem_nodes(size_t(n_elems * N));
+    int64_t                 n_noninternal = 0;
+    check(l3k_elevate_order(ctx.get(), n_elems, conn.data(), n_vertices, order, elem_nodes.data(), &n_nodes, &n_noninternal));
+    return elem_nodes;
+}
+
+// save(comm, mesh, solution_manager, path, inds, comment) / Loader::loadResults of post/NativeIO.hpp for this rank's owned
+// nodes [node_begin, node_begin + n_local): fields = [n_fields][ld] host values
+inline void saveResults(const char* path, const char* comment, size_t n_fields, int64_t n_global_nodes, int64_t node_begin,
+                        int64_t n_local, const double* fields, size_t ld, bool write_header = true)
+{
+    check(l3k_results_save(path, comment, n_fields, n_global_nodes, node_begin, n_local, fields, ld, write_header ? 1 : 0));
+}
+inline std::vector< double > loadResults(const char* path, size_t field, std::span< const int64_t > node_ids)
+{
+    std::vector< double > out(node_ids.size());
+    check(l3k_results_load(path, field, int64_t(node_ids.size()), node_ids.data(), 0, out.data()));
+    return out;
+}
 } // namespace l3k
 #endif

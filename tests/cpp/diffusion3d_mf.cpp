@@ -169,6 +169,57 @@ int main()
         std::printf("PCG: %d iterations, achieved %.2e, |Ax-b|/|b| = %.2e\n", res.iterations, res.achieved_tol, std::sqrt(e2 / b2));
         failures += !(std::sqrt(e2 / b2) < 1e-9);
     }
+    { // (5) <x, A x> from the operator's own pass, order elevation on the device, results file round trip
+        constexpr int   p = 4, U = 4, ne = 3;
+        l3k::CubeMesh   mesh{{ne, ne, ne}, p, {1, 1, 1}, 0, 0.1};
+        const int       unk0[1] = {0};
+        const auto      mask    = mesh.dirichletMask(U, unk0, 0x3f);
+        l3k::DeviceMesh dmesh{ctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        const size_t          n = size_t(dmesh.nOwnedDofs());
+        std::vector< double > x(n);
+        for (auto& v : x)
+            v = dist(prng);
+        DevVec dx{n}, dy{n}, ds{8};
+        dx.up(x);
+        sys.applyEnergy(dx.p, dy.p, ds.p);
+        ctx.synchronize();
+        const auto y = dy.down(), sblock = ds.down();
+        double     xy = 0.;
+        for (size_t i = 0; i < n; ++i)
+            xy += x[i] * y[i];
+        std::printf("<x, A x>: from the apply %.15e, dot product %.15e\n", sblock[1], xy);
+        failures += !(std::fabs(sblock[1] - xy) < 1e-11 * std::fabs(xy));
+
+        // the same cube as an order-1 connectivity, elevated on the device: (ne*p + 1)^3 nodes
+        std::vector< uint32_t > conn;
+        const auto              vid = [&](int i, int j, int k) { return uint32_t(i + (ne + 1) * (j + (ne + 1) * k)); };
+        for (int k = 0; k < ne; ++k)
+            for (int j = 0; j < ne; ++j)
+                for (int i = 0; i < ne; ++i)
+                    for (int v = 0; v < 8; ++v)
+                        conn.push_back(vid(i + (v & 1), j + ((v >> 1) & 1), k + (v >> 2)));
+        int64_t    n_nodes = 0;
+        const auto en      = l3k::elevateOrder(ctx, conn, (ne + 1) * (ne + 1) * (ne + 1), p, n_nodes);
+        std::printf("elevated %d^3 hexes to order %d: %lld nodes\n", ne, p, (long long)n_nodes);
+        failures += !(n_nodes == int64_t(ne * p + 1) * (ne * p + 1) * (ne * p + 1) && en.size() == size_t(ne * ne * ne) * 125);
+
+        // results file: two fields of the solution vector, saved as two ranks' slices, loaded back by node id
+        const int64_t         nn = int64_t(n) / U, half = nn / 2;
+        std::vector< double > f(2 * size_t(nn));
+        for (int64_t i = 0; i < nn; ++i)
+            f[size_t(i)] = y[size_t(i) * U], f[size_t(nn + i)] = y[size_t(i) * U + 2];
+        const char* path = "/tmp/l3k_cpp_test.res";
+        l3k::saveResults(path, "from the C++ shim", 2, nn, half, nn - half, f.data() + half, size_t(nn), false);
+        l3k::saveResults(path, "from the C++ shim", 2, nn, 0, half, f.data(), size_t(nn), true);
+        const std::vector< int64_t > ids{nn - 1, 0, half, half - 1};
+        const auto                   back = l3k::loadResults(path, 1, ids);
+        bool                         same = true;
+        for (size_t i = 0; i < ids.size(); ++i)
+            same = same && back[i] == y[size_t(ids[i]) * U + 2];
+        std::printf("results file round trip: %s\n", same ? "ok" : "MISMATCH");
+        failures += !same;
+    }
     try
     { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)
         l3k::CubeMesh         mesh{{1, 1, 1}, 2};
