@@ -29,9 +29,10 @@ class PartitionedMesh:
         self.order, self.rank, self.parts = order, rank, (world, 1, 1)
         # ownership: lowest part touching the node (SegmentedOwnership / the METIS-based distribution's rule)
         owner = np.full(n_nodes, world, dtype=np.int64)
-        np.minimum.at(owner, en.reshape(-1), np.repeat(part, N))
+        for q in range(world - 1, -1, -1):  # descending: the lowest part writes last
+            owner[en[part == q].reshape(-1)] = q
         # new global ids: rank-major, inside a rank ascending old id (non-internal ids are all below the internal ones)
-        order_idx = np.lexsort((np.arange(n_nodes), owner))
+        order_idx = np.argsort(owner, kind="stable")
         new_gid = np.empty(n_nodes, dtype=np.int64)
         new_gid[order_idx] = np.arange(n_nodes)
         counts = np.bincount(owner, minlength=world + 1)[:world]
