@@ -9,9 +9,10 @@ Conventions (the ones the device path wants): a node is owned by the lowest part
 contiguous global range, ranks in ascending order; inside a rank the non-internal nodes come first, then the
 element-internal nodes contiguous per element; local numbering [owned | ghosts sorted by global id]; elements whose nodes
 are all owned ("interior") first.  The result has the attributes of system.CubePartition that DeviceMesh, HaloPlan and
-DistributedOperator use.  Host code (numpy); sized for meshes up to ~10^8 nodes.
+DistributedOperator use.  The index work is torch array code that runs on the GPU.
 """
 import numpy as np
+import torch
 
 from . import system
 
@@ -19,52 +20,54 @@ from . import system
 class PartitionedMesh:
     dim = 3
 
-    def __init__(self, elem_nodes, elem_verts, n_noninternal, elem_part, rank, world, order):
+    def __init__(self, elem_nodes, elem_verts, n_noninternal, elem_part, rank, world, order, device=None):
         """elem_nodes: [n_elems][(order+1)^3] global node ids numbered [non-internal | internal, contiguous per element]
-        (what system.elevate_order returns); elem_verts [n_elems][8][3]; elem_part [n_elems] in [0, world)."""
-        en = np.ascontiguousarray(elem_nodes, dtype=np.int64)
-        part = np.ascontiguousarray(elem_part, dtype=np.int64)
+        (what system.elevate_order returns); elem_verts [n_elems][8][3]; elem_part [n_elems] in [0, world).  The index
+        work (sorts, uniques, searches over the global node table) runs in torch on `device` (default: the GPU if there
+        is one); the attributes are numpy arrays like CubePartition's."""
+        dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        en = torch.as_tensor(np.ascontiguousarray(elem_nodes).astype(np.int64), device=dev)
+        part = torch.as_tensor(np.ascontiguousarray(elem_part).astype(np.int64), device=dev)
         n_elems, N = en.shape
         n_nodes = int(en.max()) + 1 if n_elems else 0
         self.order, self.rank, self.parts = order, rank, (world, 1, 1)
         # ownership: lowest part touching the node (SegmentedOwnership / the METIS-based distribution's rule)
-        owner = np.full(n_nodes, world, dtype=np.int64)
+        owner = torch.full((n_nodes,), world, dtype=torch.int64, device=dev)
         for q in range(world - 1, -1, -1):  # descending: the lowest part writes last
             owner[en[part == q].reshape(-1)] = q
         # new global ids: rank-major, inside a rank ascending old id (non-internal ids are all below the internal ones)
-        order_idx = np.argsort(owner, kind="stable")
-        new_gid = np.empty(n_nodes, dtype=np.int64)
-        new_gid[order_idx] = np.arange(n_nodes)
-        counts = np.bincount(owner, minlength=world + 1)[:world]
-        base = np.concatenate([[0], np.cumsum(counts)])
-        self.global_node_base, self.n_global_nodes = int(base[rank]), int(n_nodes)
-        self.n_owned_nodes = int(counts[rank])
+        order_idx = torch.sort(owner, stable=True).indices
+        new_gid = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+        new_gid[order_idx] = torch.arange(n_nodes, device=dev)
+        counts = torch.bincount(owner, minlength=world + 1)[:world]
+        base = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)])
+        b0, b1 = int(base[rank]), int(base[rank + 1])
+        self.global_node_base, self.n_global_nodes, self.n_owned_nodes = b0, int(n_nodes), b1 - b0
         mine = part == rank
         E = new_gid[en[mine]]  # my elements in new global ids
-        touched = np.unique(E)
-        ghosts = touched[(touched < base[rank]) | (touched >= base[rank + 1])]  # sorted by global id
-        self.n_ghost_nodes = int(ghosts.size)
+        touched = torch.unique(E)
+        ghosts = touched[(touched < b0) | (touched >= b1)]  # sorted by global id
+        self.n_ghost_nodes = int(ghosts.numel())
         # local ids: owned = gid - base, ghosts behind them in global-id order
-        loc = np.searchsorted(ghosts, E)
-        is_owned = (E >= base[rank]) & (E < base[rank + 1])
-        local = np.where(is_owned, E - base[rank], self.n_owned_nodes + loc)
-        interior = is_owned.all(axis=1)
-        perm = np.concatenate([np.nonzero(interior)[0], np.nonzero(~interior)[0]])  # interior elements first, stable
-        self.elem_nodes = np.ascontiguousarray(local[perm].astype(np.uint32))
-        self.elem_verts = np.ascontiguousarray(np.asarray(elem_verts, dtype=np.float64)[mine][perm])
-        self.elem_global = np.nonzero(mine)[0][perm]  # index of each local element in the global mesh
+        is_owned = (E >= b0) & (E < b1)
+        local = torch.where(is_owned, E - b0, self.n_owned_nodes + torch.searchsorted(ghosts, E))
+        interior = is_owned.all(dim=1)
+        perm = torch.cat([torch.nonzero(interior).reshape(-1), torch.nonzero(~interior).reshape(-1)])  # interior first, stable
+        self.elem_nodes = np.ascontiguousarray(local[perm].cpu().numpy().astype(np.uint32))
+        mine_idx = torch.nonzero(mine).reshape(-1)[perm].cpu().numpy()
+        self.elem_verts = np.ascontiguousarray(np.asarray(elem_verts, dtype=np.float64)[mine_idx])
+        self.elem_global = mine_idx  # index of each local element in the global mesh
         self.n_elems, self.n_interior_elems = int(mine.sum()), int(interior.sum())
         # partition-independent node id of every local node (the OLD global id): for synthetic data and comparisons
-        old_of_new = order_idx
-        self.node_grid_id = np.concatenate([old_of_new[base[rank]:base[rank + 1]], old_of_new[ghosts]])
+        self.node_grid_id = torch.cat([order_idx[b0:b1], order_idx[ghosts]]).cpu().numpy()
         # neighbours.  Import receive / export send: my ghosts, grouped by owner (contiguous: global ids are rank-major)
-        ghost_owner = np.searchsorted(base, ghosts, side="right") - 1
+        ghost_owner = (torch.searchsorted(base, ghosts, right=True) - 1).cpu().numpy()
         # import send / export receive: my owned nodes that elements of other parts touch, per part, ascending local id
         other = ~mine
         en_o = new_gid[en[other]]
-        sel = (en_o >= base[rank]) & (en_o < base[rank + 1])
-        q_of = np.repeat(part[other], N).reshape(en_o.shape)[sel]
-        pairs = np.unique(np.stack([q_of, en_o[sel] - base[rank]], axis=1), axis=0) if sel.any() else np.zeros((0, 2), np.int64)
+        sel = (en_o >= b0) & (en_o < b1)
+        q_of = part[other][:, None].expand(-1, N)[sel]
+        pairs = torch.unique(torch.stack([q_of, en_o[sel] - b0], dim=1), dim=0).cpu().numpy() if bool(sel.any()) else np.zeros((0, 2), np.int64)
         nbrs = sorted(set(ghost_owner.tolist()) | set(pairs[:, 0].tolist()))
         self.nbr_rank, self.send_nodes, self.ghost_ranges = [], [], []
         for q in nbrs:
