@@ -79,3 +79,27 @@ class PartitionedMesh:
     n_local_nodes = system.CubePartition.n_local_nodes
     node_coords = system.CubePartition.node_coords
     synthetic_vector = system.CubePartition.synthetic_vector
+
+
+def rcb_partition(elem_verts, n_parts):
+    """Recursive coordinate bisection of the element centroids into n_parts parts of (nearly) equal element counts: the
+    stand-in for mesh::partitionMesh (mesh/PartitionMesh.hpp:142-183, METIS_PartMeshNodal) when no partition vector comes
+    from outside.  Splits along the longest extent of the current set, proportionally to the parts on either side, so any
+    n_parts works.  Returns int64 [n_elems]."""
+    c = np.asarray(elem_verts, dtype=np.float64).mean(axis=1)
+    out = np.zeros(c.shape[0], dtype=np.int64)
+
+    def split(idx, first, n):
+        if n == 1:
+            out[idx] = first
+            return
+        pts = c[idx]
+        axis = int(np.argmax(pts.max(axis=0) - pts.min(axis=0)))
+        n_left = n // 2
+        k = int(round(idx.size * n_left / n))
+        order = np.argsort(pts[:, axis], kind="stable")
+        split(idx[order[:k]], first, n_left)
+        split(idx[order[k:]], first + n_left, n - n_left)
+
+    split(np.arange(c.shape[0]), 0, int(n_parts))
+    return out

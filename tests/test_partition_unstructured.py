@@ -98,6 +98,25 @@ def test_partition_invariants(world, p):
             assert np.all(np.diff(m.send_nodes[k]) > 0)
 
 
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+def test_rcb_partition_balances_and_separates(n_parts):
+    verts, conn, _ = gmsh_cube()
+    ev = verts[conn.astype(np.int64)]
+    part = partition.rcb_partition(ev, n_parts)
+    counts = np.bincount(part, minlength=n_parts)
+    assert counts.sum() == conn.shape[0] and counts.max() - counts.min() <= n_parts  # equal counts up to rounding
+    if n_parts == 8:
+        # three levels of bisection of a cube: the parts are the octants, so the number of nodes shared between parts stays
+        # near the three cutting planes
+        en, n_nodes, n_nonint = ONP.elevate_order(conn, verts.shape[0], 1)
+        touch_lo = np.full(n_nodes, 99)
+        touch_hi = np.full(n_nodes, -1)
+        np.minimum.at(touch_lo, en.reshape(-1), np.repeat(part, 8))
+        np.maximum.at(touch_hi, en.reshape(-1), np.repeat(part, 8))
+        shared = int((touch_lo != touch_hi).sum())
+        assert shared < 0.25 * n_nodes
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
