@@ -212,3 +212,28 @@ def test_partitioned_apply_on_device_elevated_mesh(world, p):
         y, gid = out[r]
         rows = np.array([row_of[int(g)] for g in gid])
         assert rel_err(y.reshape(-1, U), y_ref[rows]) < 1e-12
+
+
+def test_gmsh_reader_on_a_two_hex_file(tmp_path):
+    """l3ster_amd.gmsh.read_hexes: gmsh 4.1 ASCII, node tags not contiguous, a boundary quad block that is skipped, the gmsh
+    corner order turned into v = i + 2j + 4k (positive Jacobian with the reference's vertex convention)."""
+    from l3ster_amd import gmsh
+    pts = {10: (0, 0, 0), 11: (1, 0, 0), 12: (1, 1, 0), 13: (0, 1, 0), 20: (0, 0, 1), 21: (1, 0, 1), 22: (1, 1, 1), 23: (0, 1, 1),
+           30: (2, 0, 0), 31: (2, 1, 0), 32: (2, 0, 1), 33: (2, 1, 1)}
+    tags = list(pts)
+    txt = ["$MeshFormat", "4.1 0 8", "$EndMeshFormat", "$Nodes", f"1 {len(tags)} 10 33", f"3 1 0 {len(tags)}"]
+    txt += [str(t) for t in tags] + [" ".join(str(float(c)) for c in pts[t]) for t in tags] + ["$EndNodes", "$Elements", "2 3 1 3"]
+    txt += ["2 1 3 1", "1 10 11 12 13"]  # a quad of the boundary: ignored
+    txt += ["3 7 5 2", "2 10 11 12 13 20 21 22 23", "3 11 30 31 12 21 32 33 22", "$EndElements", ""]
+    path = tmp_path / "two.msh"
+    path.write_text("\\n".join(txt))
+    verts, conn, ent = gmsh.read_hexes(path)
+    assert verts.shape == (12, 3) and conn.shape == (2, 8) and list(ent) == [7, 7]
+    v = verts[conn.astype(np.int64)]
+    # local vertex v = i + 2j + 4k: edges 0->1, 0->2, 0->4 are the x, y, z directions of these axis-aligned hexes
+    for e in range(2):
+        assert np.allclose(v[e, 1] - v[e, 0], (1, 0, 0)) and np.allclose(v[e, 2] - v[e, 0], (0, 1, 0)) and np.allclose(v[e, 4] - v[e, 0], (0, 0, 1))
+        assert np.allclose(v[e, 7] - v[e, 0], (1, 1, 1))
+    assert np.allclose(v[1, 0], (1, 0, 0))
+    en, n_nodes, _ = ONP.elevate_order(conn, verts.shape[0], 2)
+    assert n_nodes == 5 * 3 * 3  # two hexes sharing a face at order 2
