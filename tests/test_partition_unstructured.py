@@ -226,7 +226,7 @@ def test_gmsh_reader_on_a_two_hex_file(tmp_path):
     txt += ["2 1 3 1", "1 10 11 12 13"]  # a quad of the boundary: ignored
     txt += ["3 7 5 2", "2 10 11 12 13 20 21 22 23", "3 11 30 31 12 21 32 33 22", "$EndElements", ""]
     path = tmp_path / "two.msh"
-    path.write_text("\\n".join(txt))
+    path.write_text("\n".join(txt))
     verts, conn, ent = gmsh.read_hexes(path)
     assert verts.shape == (12, 3) and conn.shape == (2, 8) and list(ent) == [7, 7]
     v = verts[conn.astype(np.int64)]
