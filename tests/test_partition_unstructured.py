@@ -237,3 +237,69 @@ def test_gmsh_reader_on_a_two_hex_file(tmp_path):
     assert np.allclose(v[1, 0], (1, 0, 0))
     en, n_nodes, _ = ONP.elevate_order(conn, verts.shape[0], 2)
     assert n_nodes == 5 * 3 * 3  # two hexes sharing a face at order 2
+
+
+@pytest.mark.gpu
+def test_unstructured_partitioned_solve_end_to_end():
+    """The whole unstructured flow on the GPU: the reference's gmsh cube ([-1,1]^3) -> coordinate bisection into 4 parts ->
+    device order elevation (order 3, rotated local frames) -> every rank's part -> Dirichlet T = x on the whole boundary ->
+    partitioned diag / rhs -> partitioned Jacobi-PCG (thread ranks): T = x, q = (1, 0, 0) exactly (tri-linear geometry:
+    the linear solution is in the space, the least-squares functional vanishes there)."""
+    import queue
+    import threading
+    from l3ster_amd import solve
+    from test_gpu_apply import ThreadTransport
+    from test_gpu_boundary import ThreadAllReduce
+    world, p = 4, 3
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    verts, conn, _ = gmsh_cube()
+    conn = rotate_elements(conn, seed=5)
+    en, n_nodes, n_nonint = system.elevate_order(ctx, conn, verts.shape[0], p)
+    ev = verts[conn.astype(np.int64)]
+    part = partition.rcb_partition(ev, world)
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    red = ThreadAllReduce(world)
+    out, errors = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            m = partition.PartitionedMesh(en, ev, n_nonint, part, rank, world, p)
+            xyz = m.node_coords()
+            on_bnd = np.any(np.abs(np.abs(xyz) - 1.0) < 1e-9, axis=1)
+            mask = np.zeros((m.n_local_nodes, U), np.uint8)
+            mask[on_bnd, 0] = 1
+            c = system.Context(0, torch.cuda.current_stream().cuda_stream)
+            mesh = system.DeviceMesh(c, m, U, mask.reshape(-1))
+            mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, [1.0, 0.0])  # k = 1, no source
+            op = DistributedOperator(mf, HaloPlan(m, U, "cuda"), transport=ThreadTransport(rank, boxes))
+            n_owned = m.n_owned_nodes * U
+            g = np.zeros((m.n_owned_nodes, U))
+            g[:, 0] = np.where(on_bnd[:m.n_owned_nodes], xyz[:m.n_owned_nodes, 0], 0.0)
+            diag, rhs = op.diag_rhs(torch.as_tensor(g.reshape(1, -1), device="cuda"))
+            x = torch.zeros(n_owned, dtype=torch.float64, device="cuda")
+            res = solve.pcg_distributed(op, c, rhs[0], x, solve.jacobi_inverse_native(c, diag), tol=1e-11,
+                                        residual_scaling="rhs", max_iters=20000, allreduce=red.bind(rank), check_every=10)
+            torch.cuda.synchronize()
+            sol = x.view(-1, U).cpu().numpy()
+            # (the operator of this sign convention has q = -k grad T)
+            out[rank] = (res.num_iters, np.abs(sol[:, 0] - xyz[:m.n_owned_nodes, 0]).max(), np.abs(np.abs(sol[:, 1]) - 1.0).max(),
+                         np.abs(sol[:, 2:]).max(), op.energy_fused)
+        except Exception as exc:  # pragma: no cover
+            errors.append((rank, repr(exc)))
+            try:
+                red.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert len({v[0] for v in out.values()}) == 1
+    for r in range(world):
+        assert out[r][1] < 1e-7 and out[r][2] < 1e-6 and out[r][3] < 1e-6, (r, out[r])
+        assert out[r][4], r  # <p, A p> came from the element kernels on every rank
