@@ -328,6 +328,13 @@ def test_operator_properties_at_full_size(ctx, ne, p):
     assert rel_err(Ax.cpu().numpy()[0, rows], ys[rows, 0]) < 1e-11
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 @pytest.mark.gpu
 def test_rccl_transport_on_one_gpu():
     """The RCCL point-to-point transport of the partitioned apply, as far as one GPU allows (see the script's docstring)."""
@@ -335,7 +342,7 @@ def test_rccl_transport_on_one_gpu():
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_exchange.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RCCL self exchange ok" in r.stdout, r.stdout + r.stderr
@@ -349,7 +356,7 @@ def test_partitioned_apply_through_rccl_on_one_gpu():
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_self_partitioned_apply.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RCCL partitioned apply ok" in r.stdout, r.stdout + r.stderr
