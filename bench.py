@@ -40,21 +40,40 @@ def algorithmic_bytes_per_dof(p, U, F=0):
     return 16.0 + (4.0 * npe + 192.0) / (p ** 3 * U) + 8.0 * F / U
 
 
+KERNEL_SOURCES = ("l3ster_amd/csrc/device/sumfact_fast.hpp", "l3ster_amd/csrc/device/sumfact_apply.hpp",
+                  "l3ster_amd/csrc/device/common.hpp", "l3ster_amd/csrc/user_kernels.hpp", "include/l3k/kernel_interface.hpp")
+TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the dominant kernel: a committed PMC measurement is only quoted for the kernel it was
+    taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(ne, p):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md prescribes), or None when no profile of this workload is committed."""
+    """(HBM bytes per launch, source) of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE /
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  The profile records the hash of the
+    kernel sources it was taken at; for another workload or other sources the traffic is None (not measured)."""
+    src = {"profile": TRAFFIC_PROFILE, "kernel_source_sha256": kernel_source_hash()}
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        if t["workload"] == f"{ne}x{ne}x{ne} order {p}":
-            return t["traffic_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
+        src["profile_kernel_source_sha256"] = t.get("kernel_source_sha256")
+        if t["workload"] == f"{ne}x{ne}x{ne} order {p}" and t.get("kernel_source_sha256") == src["kernel_source_sha256"]:
+            return t["traffic_bytes_per_launch"], dict(src, status="measured on these kernel sources")
+        return None, dict(src, status="stale: profile taken on another workload or other kernel sources")
+    except Exception as e:  # no profile committed
+        return None, dict(src, status=f"no profile: {e.__class__.__name__}")
 
 
-def cpu_baseline(p, U, seconds_target=15.0):
+def cpu_baseline(part, mask, x_owned, p, U, applies=3):
     """The CPU oracle (port of the reference algorithm: per-element gather, sum-factorised sweeps in the reference's
-    order, atomic scatter, element loop over all host threads) timed on a bounded sample of the same workload."""
+    order, atomic scatter, element loop over the host threads) timed on the benchmark mesh itself with the benchmark's
+    x (same mesh, same x, all host cores the affinity mask gives): `applies` applies, median."""
     import oracle_lib as O
     from helpers import oracle_mesh
     so = "/tmp/liboracle_native.so"
@@ -65,26 +84,21 @@ def cpu_baseline(p, U, seconds_target=15.0):
     except Exception:  # pragma: no cover - fall back to the prebuilt x86-64-v3 library
         L = O.lib()
         flavour = "-O3 -march=x86-64-v3"
-    # the GPU box gives one GPU a share of 16 host cores; never oversubscribe beyond that
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    ne = 8
-    part = system.CubePartition(ne, p, perturb=0.1)
-    mask = part.dirichlet_mask(U)
+    cores = len(os.sched_getaffinity(0))  # every core the affinity mask gives (printed)
     om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
-    x = np.asfortranarray(part.synthetic_vector(U).T)
+    x = np.asfortranarray(x_owned.reshape(-1, 1))
     y = np.zeros_like(x, order="F")
-    O.mf_apply(om, 0, x, y, nthreads=cores, L=L)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
+    times = []
+    for _ in range(applies):
+        t0 = time.perf_counter()
         O.mf_apply(om, 0, x, y, nthreads=cores, L=L)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds_target or n >= 2000:
-            break
+        times.append(time.perf_counter() - t0)
     dofs = part.n_global_nodes * U
-    return {"value": dofs * n / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
-            "sample": f"{n} applies of the same kernel on a {ne}^3-element order-{p} block ({dofs} dofs), "
-                      f"oracle/oracle.cpp orc_mf_apply {flavour}, {cores} threads, {dt:.1f} s"}, (part, mask, x, y)
+    dt = float(np.median(times))
+    return {"value": dofs / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"median of {applies} applies on the benchmark mesh itself ({part.n_elems} order-{p} elements, {dofs} dofs, "
+                      f"the benchmark's x), oracle/oracle.cpp orc_mf_apply {flavour}, {cores} threads "
+                      f"(all cores of the affinity mask), {' / '.join(f'{t:.2f}' for t in times)} s"}, y
 
 
 def main():
@@ -97,8 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    # the live parity sample below (8^3 elements) must run the kernel that is being timed, not the small-launch route
-    os.environ["L3K_GENERIC_BELOW"] = "0"
+    os.environ["L3K_GENERIC_BELOW"] = "0"  # small --ne runs time the kernel named in the roofline object, not the small-launch route
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -182,17 +195,20 @@ def main():
     if rank == 0:
         # the dominant kernel launch of rank 0: all elements (one GPU) or the interior elements (partitioned), HIP events
         # on the launch stream inside the timed region; algorithmic bytes = 17.81 B per dof of the elements it processes
-        ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        kernel_times = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+        ms = float(np.median(kernel_times))  # median of the timed launches
         n_launch_elems = part.n_interior_elems // 2 if op is not None else part.n_elems  # (partitioned: the first half)
         launch_dofs = n_launch_elems * p ** 3 * U if op is not None else global_dofs
         alg_bytes = bpd * launch_dofs
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         flop_per_elem = FP64_FLOP_PER_ELEM.get(p)
+        traffic, traffic_source = measured_traffic(args.ne, p) if world == 1 else (None, None)
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": measured_traffic(args.ne, p) if world == 1 else None,
+                              "traffic": traffic, "traffic_source": traffic_source,
                               "kernel": "sumfactFastKernel" + (" (first half of the interior elements of rank 0)" if op is not None else ""),
-                              "kernel_ms": ms, "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
+                              "kernel_ms": ms, "kernel_ms_mean": float(np.mean(kernel_times)), "kernel_ms_stat": "median of the timed launches",
+                              "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
                               "algorithmic_bytes_per_launch": alg_bytes,
                               "fp64_note": "the kernel is FP64-VALU bound, not HBM bound (DESIGN.md 4.1): executed vector "
                                            "FP64 flops per element from the ISA, peak = 78.6 TFLOP/s spec (57.5 measured, "
@@ -246,17 +262,14 @@ def main():
             del mf4, X4, Y4, part4
         if world == 1 and op is None:
             if not args.no_cpu_baseline:
-                base, (spart, smask, sx, sy) = cpu_baseline(p, U)
+                # the CPU run doubles as a full-size parity check: the whole output vector of the timed GPU launches
+                # (dynamic XCD-chunked batch distribution included) against the oracle on the same mesh and x
+                base, y_cpu = cpu_baseline(part, mask, X.cpu().numpy().reshape(-1), p, U)
                 result["cpu_baseline"] = base
-                # the sample doubles as a live parity check of the GPU path against the oracle
-                smesh = system.DeviceMesh(ctx, spart, U, smask)
-                smf = system.MatrixFreeSystem(smesh, kid, [1.0, 1.0])
-                SX = torch.as_tensor(np.ascontiguousarray(sx.T), device=dev)
-                SY = torch.empty_like(SX)
-                smf.apply(SX, SY)
-                torch.cuda.synchronize()
-                err = np.linalg.norm(SY.cpu().numpy().T - sy) / np.linalg.norm(sy)
-                result["config"]["parity_vs_oracle_rel_l2"] = float(err)
+                y_gpu = Y.cpu().numpy().reshape(-1)
+                err = float(np.linalg.norm(y_gpu - y_cpu[:, 0]) / np.linalg.norm(y_cpu[:, 0]))
+                result["config"]["parity_vs_oracle_rel_l2"] = err
+                result["config"]["parity_sample"] = "the whole output vector of the benchmark mesh"
                 if not err < 1e-11:
                     raise SystemExit(f"GPU result differs from the oracle: rel L2 {err}")
         print(json.dumps(result), flush=True)

@@ -12,7 +12,7 @@
 
 #include <cstddef>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define L3K_HD __host__ __device__ __attribute__((always_inline)) inline
 #else
 #define L3K_HD inline
