@@ -434,9 +434,20 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     u0[k][NF] = 0.;
             }
         }
-        if (w_all)
+        // vertices: requested here (one coordinate per lane), used at the quadrature stage: the load's latency is never
+        // waited for.  Teams of fewer than 24 lanes (orders <= 3) store them to the team's LDS block right away
+        constexpr bool VREG = TEAM >= 24;
+        double         vreg = 0.;
+        if constexpr (VREG)
+        {
+            if (l < 24)
+                vreg = a.elem_verts[elemOf(batch) * 24 + opaqueCopy(l)];
+        }
+        else
+        {
             for (int t = opaqueCopy(l); t < 24; t += TEAM)
                 vs[t] = a.elem_verts[elemOf(batch) * 24 + t];
+        }
 
         // ---- S1: z interpolation in registers; write (c=i, b=j, a=qz) into bufA
         if (w_nn)
@@ -619,9 +630,33 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         if (w_qq)
         {
             [[maybe_unused]] double en = 0.; // ENERGY: this pencil's share of x^T A x
-            const double wyz = opaqueCopy(wyz_l); // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers)
+            // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers.)  alpha rides on the weight, so the
+            // staged result needs no scaling pass; the ENERGY variant accumulates the unscaled x^T A x and scales at the end
+            const double wyz = opaqueCopy(wyz_l) * (ENERGY ? 1. : a.alpha);
             double       G[6][3];
-            hexPencilGeom(vs, eta_l, zeta_l, G);
+            if constexpr (VREG && EW == 1)
+            {
+                // one element per wave: the coordinates are wave-uniform -- lane t's value read into SGPRs (v_readlane), which
+                // the geometry's FMAs take as operands: no LDS round trips (the LDS path read them back in 8 dependent steps)
+                double vtx[24];
+#pragma unroll
+                for (int t = 0; t < 24; ++t)
+                {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(vreg), t), hi = __builtin_amdgcn_readlane(__double2hiint(vreg), t);
+                    vtx[t]       = __hiloint2double(hi, lo);
+                }
+                hexPencilGeom(vtx, eta_l, zeta_l, G);
+            }
+            else
+            {
+                if constexpr (VREG)
+                {
+                    if (l < 24)
+                        vs[l] = vreg;
+                    stageFence();
+                }
+                hexPencilGeom(vs, eta_l, zeta_l, G);
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
             {
@@ -666,23 +701,38 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         }
         stageFence();
         L3K_STAMP(6);
-        // ---- S8: C^T along eta in place in bufB (lane (qx,qz)); S9: C^T along zeta in place in bufA (lane (qx,qy))
+        // ---- S8: C^T along eta in place in bufB (lane (qx,qz)); S9: C^T along zeta (lane (qx,qy)) added onto it: bufB then
+        // holds g2 + g3 and the x-pencil stage reads one array (its 28 reads of two arrays came out one at a time, each with
+        // its own LDS round trip, because v and dxi fill the register file there)
         if (w_qq)
         {
             double tCt[2 * HQ * HQ];
             loadTable(tCt, eoCt + opaqueZero());
+            double e0[UG][NQ], e1[UG][NQ];
 #pragma unroll
             for (int g = 0; g < UG; ++g)
-            {
-                // both pencils of the group are read before the first is swept (disjoint buffers)
-                double e0[NQ], e1[NQ], z0[NQ], z1[NQ], o0[NQ], o1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
                     const double2 t = ldg(bufB, g, at(qa, q, qb));
-                    e0[q] = t.x;
-                    e1[q] = t.y;
+                    e0[g][q] = t.x;
+                    e1[g][q] = t.y;
                 }
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+            {
+                double o0[NQ], o1[NQ];
+                sweepEO< NQ, NQ, true, false >(e0[g], o0, tCt);
+                sweepEO< NQ, NQ, true, false >(e1[g], o1, tCt);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
+            }
+            stageFence();
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+            {
+                double z0[NQ], z1[NQ], b0[NQ], b1[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
@@ -690,16 +740,18 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     z0[q] = t.x;
                     z1[q] = t.y;
                 }
-                sweepEO< NQ, NQ, true, false >(e0, o0, tCt);
-                sweepEO< NQ, NQ, true, false >(e1, o1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
-                sweepEO< NQ, NQ, true, false >(z0, o0, tCt);
-                sweepEO< NQ, NQ, true, false >(z1, o1, tCt);
+                {
+                    const double2 t = ldg(bufB, g, at(qa, qb, q));
+                    b0[q] = t.x;
+                    b1[q] = t.y;
+                }
+                sweepEO< NQ, NQ, true, true >(z0, b0, tCt);
+                sweepEO< NQ, NQ, true, true >(z1, b1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
+                    stg(bufB, g, at(qa, qb, q), b0[q], b1[q]);
             }
         }
         stageFence();
@@ -716,11 +768,11 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
-                    const double2 te = ldg(bufB, g, at(q, qa, qb)), tz = ldg(bufA, g, at(q, qa, qb));
+                    const double2 tb = ldg(bufB, g, at(q, qa, qb));
                     r10[q] = dxi[q][2 * g];
                     r11[q] = dxi[q][2 * g + 1];
-                    w0[q]  = v[q][2 * g] + te.x + tz.x;
-                    w1[q]  = v[q][2 * g + 1] + te.y + tz.y;
+                    w0[q]  = v[q][2 * g] + tb.x;
+                    w1[q]  = v[q][2 * g + 1] + tb.y;
                 }
                 sweepEO< NQ, NQ, true, true >(r10, w0, tCt);
                 sweepEO< NQ, NQ, true, true >(r11, w1, tCt);
@@ -818,7 +870,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 {
                     const uint32_t slot = (k & 1) ? sw[k >> 1] >> 16 : sw[k >> 1] & 0xffffu;
                     double*        dstl = sb + slot * U + 2 * g;
-                    *reinterpret_cast< double2* >(dstl) = make_double2(a.alpha * o0[k], a.alpha * o1[k]); // (U is even)
+                    *reinterpret_cast< double2* >(dstl) = ENERGY ? make_double2(a.alpha * o0[k], a.alpha * o1[k]) : make_double2(o0[k], o1[k]); // (U is even)
                 }
             }
             }
@@ -916,12 +968,61 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * (U / 2) + SG - 1) / SG;
             if (a.fuse_beta && !flagged)
             {
+#ifdef L3K_ABLATION
 #pragma unroll
                 for (int r = 0; r < RS; ++r)
                     shellRound.template operator()< Cfg::NSH, false >(r);
 #pragma unroll
                 for (int r = 0; r < RX; ++r)
                     exclRound.template operator()< Cfg::NSH, false >(r);
+#else
+                // the common case in two phases: every LDS read of the element first (ids and values of all rounds: one LDS
+                // round trip instead of one per round -- the registers of the sweeps are free here), then the address
+                // arithmetic and the memory instructions back to back.  Full rounds are unconditional; only the last round
+                // of each kind has lanes beyond the end
+                constexpr int  NSHU = Cfg::NSH * U, NXH = (NN - Cfg::NSH) * (U / 2);
+                uint32_t       nid[RS], nid2[RX > 0 ? RX : 1]; // (order 1 has no exclusive slots)
+                double         val[RS];
+                double2        val2[RX > 0 ? RX : 1];
+                constexpr bool part1 = RS * SG > NSHU, part2 = RX * SG > NXH;
+                const bool     in1 = !part1 || (RS - 1) * SG + sl < NSHU, in2 = !part2 || (RX - 1) * SG + sl < NXH;
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                {
+                    nid[r] = ids1[r * (SG / U)]; // (beyond the shell range these read the exclusive slots: unused)
+                    val[r] = sb1[r * SG];
+                }
+#pragma unroll
+                for (int r = 0; r < RX; ++r)
+                    if (r + 1 < RX || in2)
+                    {
+                        nid2[r] = ids2[Cfg::NSH + r * (SG / (U / 2))];
+                        val2[r] = sb2[Cfg::NSH * (U / 2) + r * SG];
+                    }
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    if (r + 1 < RS || in1)
+                    {
+                        const int64_t node = nid[r];
+                        const int64_t dof  = node * U + sl_o;
+                        double*       dst  = !SPLIT || node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                        unsafeAtomicAdd(dst, val[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < RX; ++r)
+                    if (r + 1 < RX || in2)
+                    {
+                        double* dst = a.y + int64_t(nid2[r]) * U + sl_o2; // (exclusive nodes are owned)
+                        double2 out = val2[r];
+                        if (a.beta != 0.)
+                        {
+                            const double2 old = *reinterpret_cast< const double2* >(dst);
+                            out.x += a.beta * old.x;
+                            out.y += a.beta * old.y;
+                        }
+                        *reinterpret_cast< double2* >(dst) = out;
+                    }
+#endif
             }
             else if (a.fuse_beta)
             {
