@@ -123,6 +123,25 @@ struct AdvDiff3D
     }
 };
 
+// Mass-type kernel, A0 = I (no derivative terms), rhs = (1, 2): the known answers that pin the quadrature weight times
+// detJ in the domain path -- sum_ij K_e[(i,u),(j,u)] = volume (partition of unity), sum_i F_e[(i,u)] = rhs_u * volume.
+// Not in the reference: its least-squares solve tests hold for any positive weight per quadrature point.
+struct Mass3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 2, .n_unknowns = 2};
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In&, Out& out) const
+    {
+        auto& [operators, rhs] = out;
+        auto& [A0, Ax, Ay, Az] = operators;
+        A0(0, 0) = 1.;
+        A0(1, 1) = 1.;
+        rhs[0]   = 1.;
+        rhs[1]   = 2.;
+    }
+};
+
 // ---- boundary equation kernels: the input additionally carries the outward unit normal ----------------------------
 // 3-D twin of tests/Kernels.hpp:120-128 (adiabatic wall of the first-order diffusion system): q . n = 0
 struct Adiabatic3D
@@ -222,7 +241,8 @@ struct Unit3D
 #define L3K_FOR_EACH_KERNEL(X)                                                                                         \
     X(0, ::l3k::kernels::Diffusion3D, "diffusion3d")                                                                   \
     X(1, ::l3k::kernels::Diffusion3DVar, "diffusion3d_var")                                                            \
-    X(4, ::l3k::kernels::AdvDiff3D, "advdiff3d")
+    X(4, ::l3k::kernels::AdvDiff3D, "advdiff3d")                                                                       \
+    X(8, ::l3k::kernels::Mass3D, "mass3d")
 
 // boundary equation kernels (ids continue the numbering above; 5 is the 2-D adiabatic kernel of the CPU oracle)
 #define L3K_FOR_EACH_BOUNDARY_KERNEL(X)                                                                                \
@@ -255,7 +275,9 @@ struct Unit3D
     X(::l3k::kernels::Diffusion3DVar, 4, 5, 1)                                                                         \
     X(::l3k::kernels::AdvDiff3D, 2, 3, 1)                                                                              \
     X(::l3k::kernels::AdvDiff3D, 2, 3, 2)                                                                              \
-    X(::l3k::kernels::AdvDiff3D, 4, 5, 1)
+    X(::l3k::kernels::AdvDiff3D, 4, 5, 1)                                                                              \
+    X(::l3k::kernels::Mass3D, 3, 7, 1)                                                                                 \
+    X(::l3k::kernels::Mass3D, 2, 3, 1)
 
 #define L3K_FOR_EACH_BOUNDARY_INSTANCE(X)                                                                              \
     X(::l3k::kernels::Adiabatic3D, 2, 3, 1)                                                                            \

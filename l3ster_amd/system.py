@@ -19,6 +19,7 @@ from .capi import L3KError, check
 KERNEL_DIFFUSION3D = 0
 KERNEL_DIFFUSION3D_VAR = 1
 KERNEL_ADVDIFF3D = 4
+KERNEL_MASS3D = 8  # A0 = I: known answers for w * detJ
 KERNEL_ADIABATIC3D = 6  # boundary equation kernels
 KERNEL_ROBIN3D = 7
 RESIDUAL_DIFFUSION3D_ERROR = 0

@@ -335,6 +335,15 @@ void kRobin3D(const KIn& in, KOut& o)
     o.f(0)        = h * tinf;
 }
 
+// Mass-type kernel (A0 = I, rhs = (1, 2)): twin of l3k::kernels::Mass3D, the known answer for w * detJ in the domain path
+void kMass3D(const KIn&, KOut& o)
+{
+    o.op(0, 0, 0) = 1.;
+    o.op(0, 1, 1) = 1.;
+    o.f(0)        = 1.;
+    o.f(1)        = 2.;
+}
+
 struct KernelEntry
 {
     KParams kp;
@@ -350,7 +359,8 @@ const KernelEntry* getKernel(int id)
                                         {{3, 7, 4, 3}, kAdvDiff3D},
                                         {{2, 1, 3, 0}, kAdiabatic2D, true},
                                         {{3, 1, 4, 0}, kAdiabatic3D, true},
-                                        {{3, 1, 4, 0}, kRobin3D, true}};
+                                        {{3, 1, 4, 0}, kRobin3D, true},
+                                        {{3, 2, 2, 0}, kMass3D}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];
@@ -1251,6 +1261,70 @@ int orc_gl_rule(int nq, double* x, double* w)
     std::copy(xv.begin(), xv.end(), x);
     std::copy(wv.begin(), wv.end(), w);
     return 0;
+}
+// math/Legendre.hpp:9-49 restated: coefficients of P_n (highest power first, as math/Polynomial.hpp stores them) by the
+// three-term recurrence n P_n = (2n - 1) x P_{n-1} - (n - 1) P_{n-2} on the coefficient arrays.
+int orc_legendre_coefs(int n, double* coefs /*[n + 1]*/)
+{
+    if (n < 0)
+        return fail(-1, "n < 0");
+    std::vector< double > pm2{1.}, pm1{1., 0.}; // P_0, P_1
+    if (n == 0)
+    {
+        coefs[0] = 1.;
+        return 0;
+    }
+    for (int k = 2; k <= n; ++k)
+    {
+        std::vector< double > pk(static_cast< size_t >(k) + 1, 0.);
+        const double          a = static_cast< double >(2 * k - 1) / k, c = static_cast< double >(k - 1) / k;
+        for (int i = 0; i < k; ++i) // x * P_{k-1}: same coefficients, one power up
+            pk[i] += a * pm1[i];
+        for (int i = 0; i <= k - 2; ++i) // P_{k-2} sits two powers lower
+            pk[i + 2] -= c * pm2[i];
+        pm2 = std::move(pm1);
+        pm1 = std::move(pk);
+    }
+    std::copy(pm1.begin(), pm1.end(), coefs);
+    return 0;
+}
+// math/LagrangeInterpolation.hpp:12-43 restated: monomial coefficients (highest power first) of the polynomial through
+// (x_i, y_i), as the sum of the N polynomials with roots at all x except x_i scaled to y_i at x_i; and its evaluation by
+// Horner's rule (math/Polynomial.hpp evaluate).  The reference flags the method as accurate up to about N == 16.
+int orc_lagrange_interp(int n, const double* x, const double* y, double* coefs /*[n]*/)
+{
+    if (n < 2)
+        return fail(-1, "n < 2");
+    std::fill(coefs, coefs + n, 0.);
+    std::vector< double > l(static_cast< size_t >(n));
+    for (int i = 0; i < n; ++i)
+    {
+        std::fill(l.begin(), l.end(), 0.);
+        l[0]  = 1.;
+        int j = 0;
+        for (int r = 0; r < n; ++r)
+        {
+            if (r == i)
+                continue;
+            for (int k = j + 1; k > 0; --k)
+                l[k] -= l[k - 1] * x[r];
+            ++j;
+        }
+        double v = 0.;
+        for (int k = 0; k < n; ++k)
+            v = v * x[i] + l[k];
+        const double sc = y[i] / v;
+        for (int k = 0; k < n; ++k)
+            coefs[k] += sc * l[k];
+    }
+    return 0;
+}
+double orc_poly_eval(int n_coefs, const double* coefs, double x)
+{
+    double v = 0.;
+    for (int k = 0; k < n_coefs; ++k)
+        v = v * x + coefs[k];
+    return v;
 }
 int orc_n_qps1d(int p, int value_order, int derivative_order)
 {

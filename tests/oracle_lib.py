@@ -89,6 +89,28 @@ def gl_rule(nq):
     return x, w
 
 
+def legendre_coefs(n):
+    """math/Legendre.hpp: coefficients of P_n, highest power first"""
+    c = np.zeros(n + 1)
+    _chk(lib().orc_legendre_coefs(n, _d(c)))
+    return c
+
+
+def lagrange_interp(x, y):
+    """math/LagrangeInterpolation.hpp: monomial coefficients (highest power first) of the interpolant"""
+    x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+    c = np.zeros(len(x))
+    _chk(lib().orc_lagrange_interp(len(x), _d(x), _d(y), _d(c)))
+    return c
+
+
+def poly_eval(coefs, x):
+    L = lib()
+    L.orc_poly_eval.restype = C.c_double
+    coefs = np.ascontiguousarray(coefs, dtype=np.float64)
+    return L.orc_poly_eval(len(coefs), _d(coefs), C.c_double(x))
+
+
 def n_qps1d(p, value_order=1, derivative_order=0):
     return lib().orc_n_qps1d(p, value_order, derivative_order)
 

@@ -89,3 +89,36 @@ def test_degenerate_element_is_an_error(ctx):
     mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D)
     with pytest.raises(system.L3KError, match="degenerate"):
         mf.local_assemble()
+
+
+@pytest.mark.parametrize("p,vo", [(3, 2), (2, 1)])
+def test_mass_kernel_pins_weight_times_jacobian(ctx, p, vo):
+    """Device twin of tests/test_reference_kats_tables.py::test_mass_kernel_pins_weight_times_jacobian: A0 = I on the
+    reference's distorted hex (tests/LocalOperatorCommon.hpp:36-59): sum_ij K_e[(i,u),(j,u)] = volume = 22/3, off-diagonal
+    unknown blocks vanish, sum_i F_e[(i,u)] = rhs_u * volume -- through l3k_local_assemble (MFMA path) and through the
+    matrix-free apply y = A * 1.  An error in the per-point weight w * detJ shows in every one of these numbers."""
+    vol = 22.0 / 3.0
+    mesh = system.DeviceMesh(ctx, SingleElementMesh(p, HEX), 2)
+    mf = system.MatrixFreeSystem(mesh, system.KERNEL_MASS3D, asm_opts=(vo, 0, 0))
+    K, Fe, _ = mf.local_assemble()
+    torch.cuda.synchronize()
+    K, Fe = K.cpu().numpy()[0], Fe.cpu().numpy()[0]
+    assert abs(K[0::2, 0::2].sum() - vol) < 1e-11 and abs(K[1::2, 1::2].sum() - vol) < 1e-11
+    assert np.abs(K[0::2, 1::2]).max() == 0.0
+    np.testing.assert_allclose([Fe[0, 0::2].sum(), Fe[0, 1::2].sum()], [vol, 2 * vol], atol=1e-11)
+    K_ref, F_ref = O.assemble_local(system.KERNEL_MASS3D, p, system.n_qps1d(p, vo), 1, HEX)
+    assert np.abs(K - K_ref).max() < 1e-12 * np.abs(K_ref).max()
+    ones = np.zeros(K.shape[0])
+    ones[0::2] = 1.0
+    for generic_below in ("0", "1000000"):  # the one-wave kernel and the generic LDS kernel
+        import os
+        os.environ["L3K_GENERIC_BELOW"] = generic_below
+        try:
+            X, Y = dev(ones[None, :]), dev(np.zeros((1, K.shape[0])))
+            mf.apply(X, Y, 1.0, 0.0)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("L3K_GENERIC_BELOW", None)
+        y = Y.cpu().numpy()[0]
+        np.testing.assert_allclose(y, K_ref @ ones, atol=1e-12)
+        assert abs(y[0::2].sum() - vol) < 1e-11 and np.abs(y[1::2]).max() < 1e-13
