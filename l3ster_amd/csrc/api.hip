@@ -185,12 +185,8 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.exclusive_node_end   = m->exclusive_end;
     a.slot_tab             = m->slot_tab.ptr;
     // dynamic batch distribution of the single-wave kernel (L3K_FAST_STATIC=1: the static deal)
-    static const bool static_deal = std::getenv("L3K_FAST_STATIC") != nullptr;
-    if (!static_deal && !mf->ctx->work_counters)
-    {
-        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&mf->ctx->work_counters), 8 * 128));
-    }
-    a.work_counters = static_deal ? nullptr : mf->ctx->work_counters;
+    const bool static_deal = std::getenv("L3K_FAST_STATIC") != nullptr; // (read per launch: the tests switch it)
+    a.work_counters        = static_deal ? nullptr : mf->ctx->work_counters;
     a.energy        = ncols == 1 ? mf->energy_target : nullptr;
     a.energy_done   = &mf->energy_done;
     a.n_shell              = m->n_shell;
@@ -504,7 +500,17 @@ int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
         return -1;
     }
     L3K_HIP(hipSetDevice(hip_device));
-    *out = new l3k_ctx{hip_device, static_cast< hipStream_t >(hip_stream)};
+    auto* ctx = new l3k_ctx{hip_device, static_cast< hipStream_t >(hip_stream)};
+    // the context's own device buffers are allocated here, with its device current: a later call may come from a thread
+    // whose current device is another one (several contexts in one process: thread-emulated ranks, a multi-GPU C++ host)
+    if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 8 * 128) != hipSuccess ||
+        hipMalloc(reinterpret_cast< void** >(&ctx->red_ws), sizeof(double) * 2 * l3k_cg_blocks) != hipSuccess)
+    {
+        delete ctx;
+        setError("l3k_ctx_create: hipMalloc of the context buffers failed");
+        return -3;
+    }
+    *out = ctx;
     return 0;
 }
 int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream)
@@ -816,6 +822,9 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         setError("l3k_mf_apply_elems: null argument");
         return -1;
     }
+    int cur_dev = -1;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev != mf->ctx->device) // (several contexts in one process)
+        L3K_HIP(hipSetDevice(mf->ctx->device));
     l3k::dev::ElemArgs a;
     if (int rc = fillArgs(mf, which, ncols, a))
         return rc;
@@ -837,7 +846,9 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     const auto misaligned = [](const void* p, size_t ld, int nc) {
         return reinterpret_cast< uintptr_t >(p) % 16 != 0 || (nc > 1 && (ld * sizeof(double)) % 16 != 0);
     };
-    if (mf->dense && // (the generic kernel behind non-dense dof layouts uses 8-byte accesses)
+    // only the one-wave kernel uses 16-byte accesses: it takes dense dof layouts with an even number of unknowns
+    // (FastCfg::feasible); every other shape runs the generic kernel with 8-byte accesses
+    if (mf->dense && mf->kp.n_unknowns % 2 == 0 &&
         (misaligned(d_x, ldx, ncols) || misaligned(d_y, ldy, ncols) ||
          (m->n_ghost_nodes > 0 && d_xghost && misaligned(d_xghost, ldxg, ncols)) ||
          (m->n_ghost_nodes > 0 && d_yghost && misaligned(d_yghost, ldyg, ncols))))

@@ -6,7 +6,7 @@ namespace
 // ---- fused vector kernels of the Jacobi-PCG iteration (solve/BelosSolvers.hpp:116-122 "Block CG" with one column +
 // solve/NativePreconditioners.hpp:36-96).  Scalars live in a device array s: 0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>.
 // Every dot product is a two-stage reduction in a fixed order (bitwise reproducible for a given grid).
-constexpr int cg_threads = 256, cg_blocks = 1024;
+constexpr int cg_threads = 256, cg_blocks = l3k_cg_blocks;
 __device__ __forceinline__ double blockSum(double v, double* sh)
 {
     sh[threadIdx.x] = v;
@@ -128,8 +128,11 @@ extern "C" {
 // ------------------------------------------------------------------------------------------------ Jacobi-PCG
 static int cgWorkspace(l3k_ctx* ctx)
 {
-    if (!ctx->red_ws)
-        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&ctx->red_ws), sizeof(double) * 2 * cg_blocks));
+    if (!ctx->red_ws) // (allocated by l3k_ctx_create on the context's device)
+    {
+        setError("context without reduction workspace");
+        return -3;
+    }
     return 0;
 }
 int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv)

@@ -25,6 +25,7 @@
 #include "sumfact_apply.hpp"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace l3k::dev
 {
@@ -1087,39 +1088,56 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     const bool  split    = !((a.xg == nullptr || a.xg == a.x + a.n_owned_dofs) && (a.yg == nullptr || a.yg == a.y + a.n_owned_dofs));
     auto        kernel   = a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
                                     : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
-    static int  n_cus    = 0;
-    static int  waves_cu = 0;
-    static bool attr_set = false;
-    if (!attr_set)
+    // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
+    // attribute of the four variants is set once on each device, under a lock
+    struct PerDevice
     {
-        const void* const variants[4] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
-                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
-                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
-                                         reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >)};
-        bool ok = true;
-        for (const void* f : variants)
-            ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;
-        if (!ok)
-        {
-            setError("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", Cfg::lds);
-            return -3;
-        }
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
-        {
-            setError("hipGetDeviceProperties failed");
-            return -3;
-        }
-        n_cus = prop.multiProcessorCount;
-        // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the 256-VGPR budget (2 per SIMD)
-        int by_lds = int((160 * 1024) / Cfg::lds);
-        waves_cu   = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::min_waves ? 4 * Cfg::min_waves : by_lds);
-        if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
-            waves_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_cu;
-        attr_set = true;
+        bool ready = false;
+        int  n_cus = 0, waves_cu = 0;
+    };
+    static PerDevice  per_device[64];
+    static std::mutex per_device_mutex;
+    int               dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64)
+    {
+        setError("device index %d not supported", dev);
+        return -3;
     }
+    int n_cus, waves_cu;
+    {
+        std::lock_guard< std::mutex > lock{per_device_mutex};
+        PerDevice&                    pd = per_device[dev];
+        if (!pd.ready)
+        {
+            const void* const variants[4] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
+                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
+                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
+                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >)};
+            bool ok = true;
+            for (const void* f : variants)
+                ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;
+            if (!ok)
+            {
+                setError("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", Cfg::lds);
+                return -3;
+            }
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            {
+                setError("hipGetDeviceProperties failed");
+                return -3;
+            }
+            pd.n_cus = prop.multiProcessorCount;
+            // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the 256-VGPR budget (2 per SIMD)
+            const int by_lds = int((160 * 1024) / Cfg::lds);
+            pd.waves_cu      = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::min_waves ? 4 * Cfg::min_waves : by_lds);
+            pd.ready         = true;
+        }
+        n_cus = pd.n_cus, waves_cu = pd.waves_cu;
+    }
+    if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
+        waves_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_cu;
     const int64_t  n_batches  = (a.elem_count + Cfg::EW - 1) / Cfg::EW;
     const int64_t  max_blocks = int64_t(n_cus) * waves_cu;
     const unsigned grid       = static_cast< unsigned >(n_batches < max_blocks ? n_batches : max_blocks);

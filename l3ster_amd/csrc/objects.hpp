@@ -83,6 +83,7 @@ struct DevBuf
 using l3k::api::DevBuf;
 using l3k::api::gridFor;
 
+inline constexpr int l3k_cg_blocks = 1024; // blocks of the PCG's two-stage reductions (api_solver.hip)
 struct l3k_ctx
 {
     int         device;

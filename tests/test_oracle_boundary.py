@@ -82,21 +82,29 @@ def _square_mesh(ne, p):
     return np.array(elem_nodes, np.uint32), np.array(elem_verts, float), coords, faces
 
 
-def test_k6_diffusion2d_end_to_end():
-    """K6 (tests/Diffusion2D.hpp): 4x4 quads of order 2 on [0,1]^2, first-order diffusion system (T, qx, qy),
+@pytest.mark.parametrize("ne", [4, 32])
+def test_k6_diffusion2d_end_to_end(ne):
+    """K6 (tests/Diffusion2D.hpp): ne x ne quads of order 2 on [0,1]^2, first-order diffusion system (T, qx, qy),
     Dirichlet T = x on left/right, adiabatic q.n = 0 boundary kernel on top/bottom; the discrete solution reproduces
-    T = x, q = (1, 0): L2 error of (T - x, dT/dx - 1, dT/dy) < 1e-8 on the domain and on the boundary."""
-    ne, p, U = 4, 2, 3
+    T = x, q = (1, 0): L2 error of (T - x, dT/dx - 1, dT/dy) < 1e-8 on the domain and on the boundary.  ne = 4 is the
+    reference's test; ne = 32 is BASELINE.json configs[0] as stated (examples/02-diffusion-2D, quad mesh 32 x 32, order 2,
+    assembled path on the CPU: 12 675 dofs), assembled sparse and solved directly."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    p, U = 2, 3
     nq = O.n_qps1d(p, 1, 0)
     elem_nodes, elem_verts, coords, faces = _square_mesh(ne, p)
     n_nodes = coords.shape[0]
     nd = n_nodes * U
-    K = np.zeros((nd, nd))
+    assert (ne, n_nodes, nd) in ((4, 81, 243), (32, 4225, 12675))
+    rows, cols, vals = [], [], []
     F = np.zeros(nd)
 
     def add(nodes, Ke, Fe):
         dofs = (nodes.astype(np.int64)[:, None] * U + np.arange(U)[None, :]).ravel()
-        K[np.ix_(dofs, dofs)] += Ke
+        rows.append(np.repeat(dofs, len(dofs)))
+        cols.append(np.tile(dofs, len(dofs)))
+        vals.append(Ke.ravel())
         F[dofs] += Fe[:, 0]
 
     for e in range(ne * ne):
@@ -104,7 +112,8 @@ def test_k6_diffusion2d_end_to_end():
     for bid in (1, 2):  # adiabatic: bottom, top
         for e, side in faces[bid]:
             add(elem_nodes[e], *O.assemble_local_side(side, O.KERNEL_ADIABATIC2D, p, nq, 1, elem_verts[e]))
-    assert np.allclose(K, K.T, atol=1e-13)
+    K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nd, nd)).tocsr()
+    assert abs(K - K.T).max() < 1e-13
     # Dirichlet T = x on left/right (unknown 0)
     dir_nodes = np.where((coords[:, 0] == 0.0) | (coords[:, 0] == 1.0))[0]
     dir_dofs = dir_nodes * U
@@ -112,7 +121,7 @@ def test_k6_diffusion2d_end_to_end():
     free = np.setdiff1d(np.arange(nd), dir_dofs)
     x = np.zeros(nd)
     x[dir_dofs] = g
-    x[free] = np.linalg.solve(K[np.ix_(free, free)], F[free] - K[np.ix_(free, dir_dofs)] @ g)
+    x[free] = spla.spsolve(K[free][:, free].tocsc(), F[free] - K[free][:, dir_dofs] @ g)
     sol = x.reshape(n_nodes, U)
     assert np.abs(sol[:, 0] - coords[:, 0]).max() < 1e-9
 
@@ -124,7 +133,7 @@ def test_k6_diffusion2d_end_to_end():
     fs = [s for b in (2, 1, 3, 4) for _, s in faces[b]]
     berr = np.sqrt(O.mf_integrate(mesh, O.RESIDUAL_LINEAR2D_ERROR, nq2, square=True, face_elem=fe, face_side=fs))
     assert np.linalg.norm(err) < 1e-8 and np.linalg.norm(berr) < 1e-8  # tests/Diffusion2D.hpp:117-119
-    # the perimeter through the same path: a sanity check that all 16 sides were visited once
+    # the perimeter through the same path: a sanity check that all 4 * ne sides were visited once
     per = O.mf_integrate(mesh, O.RESIDUAL_UNIT2D, nq2, face_elem=fe, face_side=fs)
     assert per[0] == pytest.approx(4.0, abs=1e-13)
 

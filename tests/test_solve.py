@@ -148,3 +148,90 @@ def test_apply_energy_equals_dot_product(p, ne, fast, monkeypatch):
     assert float((Y - Yr).abs().max()) <= 1e-12 * float(Yr.abs().max())
     assert abs(float(S[1]) - want) <= 1e-12 * abs(want)
     assert float(S[0]) == 7.0 and float(S[2]) == 7.0  # only slot 1 is written
+
+
+@pytest.mark.gpu
+def test_config5_partitioned_pcg_advdiff_order4():
+    """BASELINE.json configs[4] as stated, at a size the oracle solves in seconds: advection-diffusion kernel (U = 4,
+    E = 7, velocity = 3 interpolated fields), order 4, element partition over 8 ranks (2 x 2 x 2; threads
+    sharing the GPU, queues in place of RCCL), Jacobi-PCG driven by the partitioned matrix-free apply with all-reduced
+    scalars, rel. tol 1e-6 -- against the same PCG on the CPU with the oracle's operator on the whole mesh:
+    iterations to tolerance +-1, solution to 1e-7 (relative L2)."""
+    import queue
+    import threading
+    from l3ster_amd.distributed import DistributedOperator, HaloPlan
+    from test_gpu_apply import ThreadTransport
+    from test_gpu_boundary import ThreadAllReduce
+    assert torch.cuda.is_available()
+    kid, p, U, ne, parts = system.KERNEL_ADVDIFF3D, 4, 4, (4, 4, 4), (2, 2, 2)
+    kpar, tol = [1.0, 0.3, 1.0], 1e-6
+    world = int(np.prod(parts))
+
+    def velocity(xyz):  # smooth analytic velocity field at the nodes
+        return np.stack([0.2 * np.sin(np.pi * xyz[:, 1]), 0.1 * np.cos(np.pi * xyz[:, 0]), 0.05 * xyz[:, 2]])
+
+    def dirichlet_values(part, mask):  # c = x + y on the boundary
+        xyz = part.node_coords()
+        g = np.zeros((part.n_local_nodes, U))
+        g[:, 0] = xyz[:, 0] + xyz[:, 1]
+        return g.reshape(-1) * mask
+
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    red = ThreadAllReduce(world)
+    out, errors = {}, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            part = system.CubePartition(ne, p, parts, rank, perturb=0.1)
+            mask = part.dirichlet_mask(U)
+            c = system.Context(0, torch.cuda.current_stream().cuda_stream)
+            mf = system.MatrixFreeSystem(system.DeviceMesh(c, part, U, mask), kid, kpar)
+            mf.set_fields(torch.as_tensor(velocity(part.node_coords()), device="cuda"))
+            op = DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes))
+            n_owned = part.n_owned_nodes * U
+            g = torch.as_tensor(dirichlet_values(part, mask)[:n_owned], device="cuda")
+            diag, rhs = op.diag_rhs(g[None, :])
+            x = torch.zeros(n_owned, dtype=torch.float64, device="cuda")
+            res = solve.pcg_distributed(op, c, rhs[0], x, solve.jacobi_inverse_native(c, diag), tol=tol, residual_scaling="rhs",
+                                        max_iters=20000, allreduce=red.bind(rank))
+            torch.cuda.synchronize()
+            out[rank] = (res.num_iters, x.cpu().numpy(), part.node_grid_id[:part.n_owned_nodes].copy())
+        except Exception as exc:  # pragma: no cover
+            errors.append((rank, repr(exc)))
+            try:
+                red.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    # the same solve on the CPU: oracle operator on the whole mesh, torch-op PCG
+    whole = system.CubePartition(ne, p, perturb=0.1)
+    mask = whole.dirichlet_mask(U)
+    om = oracle_mesh(whole, p + 1, U, np.arange(U), mask, velocity(whole.node_coords()))
+    g = dirichlet_values(whole, mask)
+    d_ref, r_ref = O.mf_diag_rhs(om, kid, 1, np.asfortranarray(g[:, None]), kparams=kpar, nthreads=4)
+
+    def apply_cpu(v, o):
+        o.copy_(torch.as_tensor(O.mf_apply(om, kid, v.numpy().reshape(-1, 1), kparams=kpar, nthreads=4)[:, 0]))
+
+    x_ref = torch.zeros(len(d_ref), dtype=torch.float64)
+    res_ref = solve.cg(apply_cpu, torch.as_tensor(r_ref[:, 0].copy()), x_ref, solve.jacobi_inverse(torch.as_tensor(d_ref)), tol=tol,
+                       residual_scaling="rhs", max_iters=20000)
+    iters = {v[0] for v in out.values()}
+    assert len(iters) == 1, iters
+    assert abs(iters.pop() - res_ref.num_iters) <= 1, (out[0][0], res_ref.num_iters)
+    row_of = {int(gid): i for i, gid in enumerate(whole.node_grid_id)}
+    xr = x_ref.numpy().reshape(-1, U)
+    num = den = 0.0
+    for r in range(world):
+        _, x, gid = out[r]
+        rows = np.array([row_of[int(k)] for k in gid])
+        num += np.sum((x.reshape(-1, U) - xr[rows]) ** 2)
+        den += np.sum(xr[rows] ** 2)
+    assert np.sqrt(num / den) < 1e-7
