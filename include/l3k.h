@@ -284,6 +284,24 @@ int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* 
  * SURVEY.md §0 D6). */
 int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum);
 
+/* scatterLocalSystem for a batch, algsys/ScatterLocalSystem.hpp:24-54 (called per element by assembleGlobalSystem,
+ * algsys/AssembleGlobalSystem.hpp:20-53): the element matrices / right-hand sides of elements [first, first+count) -- the
+ * d_K / d_F of l3k_local_assemble, in its layouts -- are summed into the caller's global system on the device.
+ *   matrix: d_values[nnz] over the caller's CSR graph of the rank-local matrix (d_row_ptr[n_local_dofs + 1], d_col_ind[nnz]
+ *           ascending within a row; local dof numbering, rows and columns = node * dofs_per_node + field_inds[u], the
+ *           reference's row_dofs / col_dofs): values[pos(row, col)] += K_e[i][j], atomically.  What Tpetra's
+ *           sumIntoLocalValues does per element row happens here for the whole batch; the host takes the finished
+ *           values array (one setAllValues, or one sumIntoLocalValues per batch of rows).
+ *   rhs:    d_rhs[r * ldr + row] += F_e[i][r], atomically (the reference's std::atomic_ref fetch_add).
+ * Entries whose (row, col) is not in the graph are skipped and counted in *n_missing (may be NULL), as
+ * sumIntoLocalValues does.  skip_dirichlet != 0: rows and columns of dofs flagged in the mesh's Dirichlet mask are left
+ * out, which makes the assembled operator the matrix-free one on the free dofs (gather reads Dirichlet dofs as 0, scatter
+ * skips them, algsys/MatrixFreeSystem.hpp:441-466,517-536); 0 = the plain sum of the reference's assembled path.
+ * Either of (d_K, d_values) / (d_F, d_rhs) may be NULL together. */
+int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F,
+                          const int64_t* d_row_ptr, const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr,
+                          int skip_dirichlet, int64_t* n_missing);
+
 /* ---- host-side synthetic mesh + block partition --------------------------------------------------------------------
  * Stand-in for makeCubeMesh + convertMeshToOrder + partitionMesh + the ownership / import-export context
  * (mesh/primitives/CubeMesh.hpp:16-138, mesh/ConvertMeshToOrder.hpp:51-104, mesh/PartitionMesh.hpp:142-183,

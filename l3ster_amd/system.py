@@ -553,6 +553,19 @@ class MatrixFreeSystem:
         check(capi.load().l3k_local_assemble(self._h, first, count, _ptr(K), _ptr(F), _ptr(cs)))
         return K, F, cs
 
+    def assembled_scatter(self, K, F, row_ptr, col_ind, values, rhs, first=0, skip_dirichlet=False):
+        """scatterLocalSystem for the batch [first, first + len(K)) (algsys/ScatterLocalSystem.hpp:24-54): K [count, Nd, Nd]
+        and F [count, n_rhs, Nd] as local_assemble returns them, summed into `values` (over the caller's CSR graph
+        row_ptr int64 / col_ind int32, device tensors) and `rhs` [n_rhs, n_local_dofs].  Returns the number of entries
+        that were not in the graph."""
+        import ctypes as C
+        count = (K if K is not None else F).shape[0]
+        missing = C.c_int64(0)
+        check(capi.load().l3k_assembled_scatter(self._h, first, count, _ptr(K), _ptr(F), _ptr(row_ptr), _ptr(col_ind), _ptr(values),
+                                                _ptr(rhs), 0 if rhs is None else rhs.stride(0) if rhs.dim() == 2 else rhs.numel(),
+                                                int(skip_dirichlet), C.byref(missing)))
+        return missing.value
+
     def new_ghost_buffer(self, ncols, like):
         import torch
         return torch.zeros((ncols, max(self.mesh.n_ghost_dofs, 1)), dtype=torch.float64, device=like.device)

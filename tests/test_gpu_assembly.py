@@ -153,3 +153,81 @@ def test_config3_full_streaming_sweep_64cubed_order6(ctx):
         Y = O.apply_sumfact(system.KERNEL_DIFFUSION3D, p, p + 1, part.elem_verts[e], E, kparams=kpar)
         ref = float((Y * wgt).sum())
         assert abs(cs[e] - ref) < 1e-10 * float((np.abs(Y) * wgt).sum()), (e, cs[e], ref)
+
+
+def _csr_graph(part, dpn, field_inds):
+    """CSR graph of the rank-local matrix: row / column dofs of every element coupled (what the reference's sparsity graph
+    holds for one domain kernel), columns ascending -- built on the host like the caller's Tpetra graph would be."""
+    import scipy.sparse as sp
+    dofs = (part.elem_nodes.astype(np.int64)[:, :, None] * dpn + np.asarray(field_inds)[None, None, :]).reshape(part.n_elems, -1)
+    nd = dofs.shape[1]
+    rows = np.repeat(dofs, nd, axis=1).ravel()
+    cols = np.tile(dofs, (1, nd)).ravel()
+    n = part.n_local_nodes * dpn
+    G = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)).tocsr()
+    G.sort_indices()
+    return G.indptr.astype(np.int64), G.indices.astype(np.int32), n
+
+
+@pytest.mark.parametrize("kid,p,vo,R,kpar", [(system.KERNEL_DIFFUSION3D, 2, 1, 2, [0.7, 1.3]), (system.KERNEL_MASS3D, 3, 2, 1, None),
+                                             (system.KERNEL_DIFFUSION3D, 4, 1, 1, [1.0, 1.0])])
+def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar):
+    """a20, scatterLocalSystem + assembleGlobalSystem (algsys/ScatterLocalSystem.hpp:24-54, AssembleGlobalSystem.hpp:20-53)
+    on the device: local systems of a 3^3 (2^3 at order 4) distorted mesh from l3k_local_assemble summed into the caller's
+    CSR values and the global right-hand sides, in two batches; against the oracle's element systems added into a dense
+    global matrix on the host.  Then with skip_dirichlet: the assembled operator equals the matrix-free apply."""
+    import scipy.sparse as sp
+    info = system.kernel_info(kid)
+    U = info["n_unknowns"]
+    ne = 2 if p == 4 else 3
+    part = system.CubePartition(ne, p, perturb=0.15)
+    nq = system.n_qps1d(p, vo)
+    mask = part.dirichlet_mask(U) if U == 4 else None
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar, asm_opts=(vo, 0, 0), n_rhs=R)
+    row_ptr, col_ind, n = _csr_graph(part, U, np.arange(U))
+    RP, CI = torch.as_tensor(row_ptr, device="cuda"), torch.as_tensor(col_ind, device="cuda")
+
+    def assemble(skip):
+        vals = torch.zeros(len(col_ind), dtype=torch.float64, device="cuda")
+        rhs = torch.zeros((R, n), dtype=torch.float64, device="cuda")
+        half = part.n_elems // 2
+        for first, count in ((0, half), (half, part.n_elems - half)):
+            K, Fe, _ = mf.local_assemble(first, count)
+            assert mf.assembled_scatter(K, Fe, RP, CI, vals, rhs, first=first, skip_dirichlet=skip) == 0
+        torch.cuda.synchronize()
+        return sp.csr_matrix((vals.cpu().numpy(), col_ind, row_ptr), shape=(n, n)), rhs.cpu().numpy()
+
+    A, rhs = assemble(False)
+    A_ref, rhs_ref = np.zeros((n, n)), np.zeros((R, n))
+    for e in range(part.n_elems):
+        K_ref, F_ref = O.assemble_local(kid, p, nq, R, part.elem_verts[e], None, kpar)
+        dofs = (part.elem_nodes[e].astype(np.int64)[:, None] * U + np.arange(U)[None, :]).ravel()
+        A_ref[np.ix_(dofs, dofs)] += K_ref
+        rhs_ref[:, dofs] += F_ref.T
+    assert np.abs(A.toarray() - A_ref).max() < 1e-12 * np.abs(A_ref).max()
+    assert np.abs(rhs - rhs_ref).max() < 1e-12 * max(1.0, np.abs(rhs_ref).max())
+    if kid == system.KERNEL_MASS3D:  # the global mass matrix sums to the volume of the (perturbed) unit cube per unknown
+        assert abs(A.toarray()[0::2, 0::2].sum() - 1.0) < 1e-12
+    # a graph that lacks entries: they are skipped and counted (sumIntoLocalValues semantics)
+    keep = np.ones(len(col_ind), bool)
+    keep[row_ptr[5]:row_ptr[6]][::2] = False
+    rp2 = np.concatenate([[0], np.cumsum(np.add.reduceat(keep.astype(np.int64), row_ptr[:-1]))])
+    vals2 = torch.zeros(int(keep.sum()), dtype=torch.float64, device="cuda")
+    K, _, _ = mf.local_assemble(0, part.n_elems)
+    missing = mf.assembled_scatter(K, None, torch.as_tensor(rp2, device="cuda"), torch.as_tensor(col_ind[keep], device="cuda"), vals2, None)
+    assert missing > 0
+    A2 = sp.csr_matrix((vals2.cpu().numpy(), col_ind[keep], rp2), shape=(n, n)).toarray()
+    dropped = np.zeros((n, n), bool)
+    dropped[5, col_ind[row_ptr[5]:row_ptr[6]][::2]] = True
+    assert np.abs(np.where(dropped, 0.0, A_ref) - A2).max() < 1e-12 * np.abs(A_ref).max()
+    if mask is not None:
+        # assembled == matrix-free on the free dofs (the reference's cross-path property, tests/LocalOperatorTests.cpp:3-95,
+        # at mesh level): Dirichlet rows / columns left out of the sum, y[D] = x[D] added by hand
+        Af, _ = assemble(True)
+        x = part.synthetic_vector(U)
+        X, Y = dev(x), dev(np.zeros_like(x))
+        mf.apply(X, Y, 1.0, 0.0)
+        torch.cuda.synchronize()
+        want = Af @ x[0] + np.where(mask, x[0], 0.0)
+        assert np.linalg.norm(Y.cpu().numpy()[0] - want) < 1e-11 * np.linalg.norm(want)
