@@ -98,6 +98,13 @@ int l3k_instance_info(int i, int* kernel_id, int* order, int* nq, int* ncols);
  * torch.cuda.current_stream().cuda_stream. */
 int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out);
 int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream);
+/* Bitwise-reproducible mode (also: environment L3K_DETERMINISTIC=1 when the context is created).  The reference scatters
+ * with relaxed atomics (algsys/MatrixFreeSystem.hpp:513), so its global results change in the last bits from run to run
+ * and PCG iteration counts move with them; for parity runs this build can fix the order instead: meshes created while the
+ * mode is on carry a colouring of their elements (no two elements of a colour share a node) and every domain-kernel
+ * launch (apply, diag / rhs) goes colour by colour, so each row receives its contributions in a fixed order; <p, A p>
+ * comes from the fixed-order dot product.  Slower (one launch per colour); boundary terms are not covered (error). */
+int l3k_ctx_set_deterministic(l3k_ctx* ctx, int on);
 int l3k_ctx_synchronize(l3k_ctx* ctx);
 int l3k_ctx_destroy(l3k_ctx* ctx);
 

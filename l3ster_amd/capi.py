@@ -65,6 +65,7 @@ SIGNATURES = {
     "l3k_instance_info": (C.c_int, [C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
     "l3k_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "l3k_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "l3k_ctx_set_deterministic": (C.c_int, [_vp, C.c_int]),
     "l3k_ctx_synchronize": (C.c_int, [_vp]),
     "l3k_ctx_destroy": (C.c_int, [_vp]),
     "l3k_mesh_create": (C.c_int, [_vp, C.POINTER(MeshDesc), C.POINTER(_vp)]),

@@ -3,6 +3,8 @@
 // point fails with an error.
 #include "objects.hpp"
 
+#include <unordered_map>
+
 using l3k::api::KernelMeta;
 using l3k::api::findKernel;
 using l3k::api::findResidual;
@@ -366,6 +368,119 @@ int bndDiagRhsImpl(l3k_bnd* b, int which, const double* d_dirichlet_vals, size_t
 } // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
+
+namespace
+{
+// Greedy colouring of the elements by their corner nodes (two conforming hexes share a node iff they share a corner), class
+// by class in element order; the element arrays are copied in (class, colour, element) order.  A launch over one colour of
+// one class adds at most once to any row, so the order of the additions to a row is the order of the launches.
+int buildDeterministicPlan(l3k_mesh& m, const l3k_mesh_desc* d, const std::vector< uint8_t >& flags)
+{
+    const int     n1 = d->order + 1;
+    const int64_t N  = int64_t(n1) * n1 * n1;
+    int           corner[8];
+    for (int v = 0; v < 8; ++v)
+        corner[v] = ((v & 1) ? n1 - 1 : 0) + n1 * (((v >> 1) & 1) ? n1 - 1 : 0) + n1 * n1 * (((v >> 2) & 1) ? n1 - 1 : 0);
+    std::unordered_map< uint32_t, uint64_t > used; // corner node -> colours taken by the elements around it
+    used.reserve(static_cast< size_t >(d->n_elems) * 2);
+    std::vector< uint8_t > colour(static_cast< size_t >(d->n_elems));
+    int                    n_colours = 0;
+    for (int64_t e = 0; e < d->n_elems; ++e)
+    {
+        uint64_t taken = 0;
+        for (int v = 0; v < 8; ++v)
+        {
+            const auto it = used.find(d->elem_nodes[e * N + corner[v]]);
+            if (it != used.end())
+                taken |= it->second;
+        }
+        int c = 0;
+        while (c < 64 && ((taken >> c) & 1u))
+            ++c;
+        if (c == 64)
+        {
+            setError("deterministic mode: more than 64 colours needed");
+            return -1;
+        }
+        colour[e] = uint8_t(c);
+        n_colours = std::max(n_colours, c + 1);
+        for (int v = 0; v < 8; ++v)
+            used[d->elem_nodes[e * N + corner[v]]] |= uint64_t(1) << c;
+    }
+    std::vector< int64_t > order(static_cast< size_t >(d->n_elems));
+    for (int64_t e = 0; e < d->n_elems; ++e)
+        order[e] = e;
+    const int64_t n_int = d->n_interior_elems;
+    auto          by_colour = [&](int64_t x, int64_t y) { return colour[x] < colour[y]; };
+    std::stable_sort(order.begin(), order.begin() + n_int, by_colour);
+    std::stable_sort(order.begin() + n_int, order.end(), by_colour);
+    for (int cls = 0; cls < 2; ++cls)
+    {
+        const int64_t b = cls ? n_int : 0, e = cls ? d->n_elems : n_int;
+        m.det_ptr[cls].assign(static_cast< size_t >(n_colours) + 1, e);
+        int64_t i = b;
+        for (int c = 0; c < n_colours; ++c)
+        {
+            m.det_ptr[cls][c] = i;
+            while (i < e && colour[order[i]] == c)
+                ++i;
+        }
+    }
+    std::vector< uint32_t > nodes(static_cast< size_t >(d->n_elems * N));
+    std::vector< double >   verts(static_cast< size_t >(d->n_elems) * 24);
+    std::vector< uint8_t >  fl(flags.empty() ? 0 : static_cast< size_t >(d->n_elems));
+    for (int64_t i = 0; i < d->n_elems; ++i)
+    {
+        const int64_t e = order[i];
+        std::copy_n(d->elem_nodes + e * N, N, nodes.begin() + i * N);
+        std::copy_n(d->elem_verts + e * 24, 24, verts.begin() + i * 24);
+        if (!fl.empty())
+            fl[i] = flags[e];
+    }
+    hipStream_t s = m.ctx->stream;
+    if (int rc = m.det_elem_nodes.upload(nodes.data(), nodes.size(), s))
+        return rc;
+    if (int rc = m.det_elem_verts.upload(verts.data(), verts.size(), s))
+        return rc;
+    if (!fl.empty())
+        if (int rc = m.det_elem_flags.upload(fl.data(), fl.size(), s))
+            return rc;
+    L3K_HIP(hipStreamSynchronize(s)); // (the staging vectors are locals)
+    m.det_built = true;
+    return 0;
+}
+// the launch ranges of an element call: the caller's range as it is, or in deterministic mode the colours of the classes
+// it covers, on the permuted element arrays (the two halves of the interior, which = 3 / 4, become: all of it / nothing)
+template < typename F >
+int forEachLaunchRange(const l3k_mf* mf, int which, l3k::dev::ElemArgs& a, F&& launch)
+{
+    const l3k_mesh* m = mf->mesh;
+    if (!mf->ctx->deterministic)
+        return launch(a);
+    if (!m->det_built)
+    {
+        setError("deterministic mode was enabled after this mesh was created: create the mesh with the mode on");
+        return -1;
+    }
+    a.elem_nodes = m->det_elem_nodes.ptr;
+    a.elem_verts = m->det_elem_verts.ptr;
+    a.elem_flags = m->det_elem_flags.ptr;
+    a.energy     = nullptr; // (the fused <x, A x> is an atomic accumulation: the caller takes the fixed-order dot product)
+    const bool classes[2] = {which == 0 || which == 2 || which == 3, which == 1 || which == 2};
+    for (int cls = 0; cls < 2; ++cls)
+        if (classes[cls])
+            for (size_t c = 0; c + 1 < m->det_ptr[cls].size(); ++c)
+            {
+                a.elem_begin = m->det_ptr[cls][c];
+                a.elem_count = m->det_ptr[cls][c + 1] - m->det_ptr[cls][c];
+                if (a.elem_count > 0)
+                    if (int rc = launch(a))
+                        return rc;
+            }
+    return 0;
+}
+} // namespace
+
 extern "C" {
 
 int l3k_version(void)
@@ -501,6 +616,8 @@ int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
     }
     L3K_HIP(hipSetDevice(hip_device));
     auto* ctx = new l3k_ctx{hip_device, static_cast< hipStream_t >(hip_stream)};
+    if (const char* e = std::getenv("L3K_DETERMINISTIC"))
+        ctx->deterministic = std::atoi(e) != 0;
     // the context's own device buffers are allocated here, with its device current: a later call may come from a thread
     // whose current device is another one (several contexts in one process: thread-emulated ranks, a multi-GPU C++ host)
     if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 8 * 128) != hipSuccess ||
@@ -521,6 +638,16 @@ int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream)
         return -1;
     }
     ctx->stream = static_cast< hipStream_t >(hip_stream);
+    return 0;
+}
+int l3k_ctx_set_deterministic(l3k_ctx* ctx, int on)
+{
+    if (!ctx)
+    {
+        setError("null ctx");
+        return -1;
+    }
+    ctx->deterministic = on != 0;
     return 0;
 }
 int l3k_ctx_synchronize(l3k_ctx* ctx)
@@ -668,6 +795,9 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
         if (int rc = m->owned_dirichlet_rows.upload(rows.data(), rows.size(), ctx->stream))
             return rc;
     }
+    if (ctx->deterministic)
+        if (int rc = buildDeterministicPlan(*m, d, flags))
+            return rc;
     L3K_HIP(hipStreamSynchronize(ctx->stream)); // host arrays may be freed by the caller after return
     *out = m.release();
     return 0;
@@ -869,9 +999,14 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     a.fuse_beta = mf->fuse;
     const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
     const auto* inst = l3k::dev::findInstance(mf->kernel_id, mf->mesh->order, mf->nq, ncols);
+    if (mf->ctx->deterministic && !mf->boundary_terms.empty())
+    {
+        setError("deterministic mode covers the domain kernels only: this system has boundary terms attached (atomic scatter)");
+        return -1;
+    }
     if (inst)
     {
-        if (int rc = inst->apply(a, blob, mf->ctx->stream))
+        if (int rc = forEachLaunchRange(mf, which, a, [&](l3k::dev::ElemArgs& r) { return inst->apply(r, blob, mf->ctx->stream); }))
             return rc;
     }
     else
@@ -888,7 +1023,7 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
             ac.xg = d_xghost ? d_xghost + ldxg * c : nullptr;
             ac.y  = d_y + ldy * c;
             ac.yg = d_yghost ? d_yghost + ldyg * c : nullptr;
-            if (int rc = inst->apply(ac, blob, mf->ctx->stream))
+            if (int rc = forEachLaunchRange(mf, which, ac, [&](l3k::dev::ElemArgs& r) { return inst->apply(r, blob, mf->ctx->stream); }))
                 return rc;
         }
     }
@@ -1063,7 +1198,14 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
     const auto* inst = instanceFor(mf, mf->n_rhs);
     if (!inst)
         return -4;
-    if (int rc = inst->diag_rhs(a, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream))
+    if (mf->ctx->deterministic && !mf->boundary_terms.empty())
+    {
+        setError("deterministic mode covers the domain kernels only: this system has boundary terms attached (atomic scatter)");
+        return -1;
+    }
+    if (int rc = forEachLaunchRange(mf, which, a, [&](l3k::dev::ElemArgs& r) {
+            return inst->diag_rhs(r, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream);
+        }))
         return rc;
     for (l3k_bnd* b : mf->boundary_terms)
         if (int rc = bndDiagRhsImpl(b, which, d_dirichlet_vals, ldg, d_diag, d_rhs, ldr, d_diag_ghost, d_rhs_ghost, ldrg))

@@ -88,6 +88,9 @@ struct l3k_ctx
 {
     int         device;
     hipStream_t stream;
+    // bitwise-reproducible mode (L3K_DETERMINISTIC=1 or l3k_ctx_set_deterministic): element launches go colour by colour
+    // (no two elements of a launch share a node), so every row of y receives its contributions in a fixed order
+    bool        deterministic = false;
     double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
     uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes)
     ~l3k_ctx()
@@ -114,6 +117,14 @@ struct l3k_mesh
     // rows in y), slots [n_shell, N) its internal nodes = exactly the nodes of [exclusive_begin, exclusive_end)
     DevBuf< uint16_t >  slot_tab;
     int                 n_shell = 0;
+    // deterministic mode: copies of the element arrays with the elements of each class (interior, border) sorted by colour;
+    // det_ptr[0][c] .. det_ptr[0][c + 1] = interior elements of colour c, det_ptr[1][...] the border ones (positions in the
+    // permuted arrays, which keep the interior elements first)
+    bool                   det_built = false;
+    DevBuf< uint32_t >     det_elem_nodes;
+    DevBuf< double >       det_elem_verts;
+    DevBuf< uint8_t >      det_elem_flags;
+    std::vector< int64_t > det_ptr[2];
     int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
     int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
 };

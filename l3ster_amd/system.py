@@ -210,6 +210,10 @@ class Context:
     def set_stream(self, stream):
         check(capi.load().l3k_ctx_set_stream(self._h, C.c_void_p(stream or 0)))
 
+    def set_deterministic(self, on=True):
+        """Bitwise-reproducible element launches (colour by colour) for the meshes created from now on."""
+        check(capi.load().l3k_ctx_set_deterministic(self._h, int(bool(on))))
+
     def synchronize(self):
         check(capi.load().l3k_ctx_synchronize(self._h))
 

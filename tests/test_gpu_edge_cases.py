@@ -193,3 +193,51 @@ def test_static_deal_fallback():
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=dict(os.environ, L3K_FAST_STATIC="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "static deal ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,ne", [(6, 12), (4, 14), (2, 6)])
+def test_deterministic_mode_is_bitwise_reproducible(p, ne):
+    """SURVEY.md 5 (race detection): the reference's scatter uses relaxed atomics (algsys/MatrixFreeSystem.hpp:513) and its
+    global results are not bitwise reproducible; this build's deterministic mode (l3k_ctx_set_deterministic, element
+    launches colour by colour) is.  Two applies of the same x are bitwise equal, agree with the atomic mode to rounding
+    and with the oracle; diag / rhs likewise; and a PCG solve takes exactly the same number of iterations and ends in
+    exactly the same vector in three runs.  (Orders 6 and 4 at sizes that run the one-wave kernel, order 2 the generic.)"""
+    import torch
+    import oracle_lib as O
+    from helpers import oracle_mesh, rel_err
+    from l3ster_amd import solve, system
+    torch.cuda.set_device(0)
+    U, kid, kpar = 4, system.KERNEL_DIFFUSION3D, [1.0, 1.0]
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_deterministic(True)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), kid, kpar)
+    x = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=3)
+    ys = []
+    for _ in range(3):
+        y = torch.full_like(x, 0.25)
+        mf.apply(x, y, 1.5, -0.5)
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    ctx2 = system.Context(0, torch.cuda.current_stream().cuda_stream)  # the atomic mode on the same mesh
+    mf2 = system.MatrixFreeSystem(system.DeviceMesh(ctx2, part, U, mask), kid, kpar)
+    y2 = torch.full_like(x, 0.25)
+    mf2.apply(x, y2, 1.5, -0.5)
+    assert (ys[0] - y2).norm().item() < 1e-13 * y2.norm().item()
+    if part.n_elems <= 3000:
+        om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
+        y_ref = O.mf_apply(om, kid, x.cpu().numpy().T, np.full((x.shape[1], 1), 0.25, order="F"), alpha=1.5, beta=-0.5, kparams=kpar, nthreads=8)
+        assert rel_err(ys[0].cpu().numpy()[0], y_ref[:, 0]) < 1e-11
+    runs = []
+    for _ in range(3):
+        diag, rhs = mf.diag_rhs(None)
+        sol = torch.zeros_like(diag)
+        res = solve.pcg(mf, rhs[0], sol, solve.jacobi_inverse_native(ctx, diag), tol=1e-9, residual_scaling="rhs", max_iters=4000)
+        runs.append((res.num_iters, diag.clone(), rhs.clone(), sol.clone()))
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        assert torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and torch.equal(r[3], runs[0][3])
