@@ -309,6 +309,35 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
                           const int64_t* d_row_ptr, const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr,
                           int skip_dirichlet, int64_t* n_missing);
 
+/* ---- ghost exchange of a partitioned system: RCCL neighbour send / receive behind the C ABI -----------------------------
+ * Stands in for comm::Import / comm::Export and their ImportExportContext (comm/ImportExport.hpp:29-72,130-215,295-372,
+ * 402-470) and for the communication part of MatrixFreeSystem::applyImpl (algsys/MatrixFreeSystem.hpp:1046-1111).  The
+ * reference exchanges host memory through MPI; here the host passes device pointers and the library issues one
+ * ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd per direction on a stream of its own (RCCL over xGMI),
+ * ordered against the context's stream by events.  RCCL (librccl.so.1) is loaded when the first halo is created.
+ *
+ * l3k_halo_unique_id: ncclGetUniqueId (128 bytes) -- one rank calls it and hands the bytes to the others out of band (the
+ *   reference's host has MPI_Bcast for that).
+ * l3k_halo_create: collective over the `world` ranks (ncclCommInitRank).  Exchange lists as l3k_host_mesh_view holds them:
+ *   neighbour i = nbr_rank[i]; owned nodes send_nodes[send_offsets[i] .. send_offsets[i+1]) are read by it (import send,
+ *   export receive); ghost nodes [ghost_offsets[i], ghost_offsets[i+1]) (numbered from 0 behind the owned nodes) are owned
+ *   by it (import receive, export send).  A rank may list itself (periodic identification of its own nodes).
+ * l3k_halo_import:     ghost rows <- owners' rows           (owner -> sharer copy)
+ * l3k_halo_export_add: owners' rows += ghost rows           (sharer -> owner add; per neighbour in list order)
+ * l3k_mf_apply_dist:   y <- alpha A x + beta y on the owned rows, x and y [ncols][ld] over the owned rows only: scale, pack,
+ *   post import || first half of the interior elements, border elements, post export || second half of the interior
+ *   elements, unpack-add, Dirichlet rows.  Every call returns with the work queued on the context's stream. */
+typedef struct l3k_halo l3k_halo;
+int     l3k_halo_unique_id(char* id128);
+int     l3k_halo_create(l3k_ctx* ctx, const char* id128, int rank, int world, int dofs_per_node, int n_nbrs, const int* nbr_rank,
+                        const int64_t* send_offsets, const int32_t* send_nodes, const int64_t* ghost_offsets, l3k_halo** out);
+int     l3k_halo_destroy(l3k_halo* halo);
+int64_t l3k_halo_n_ghost_dofs(const l3k_halo* halo);
+int     l3k_halo_import(l3k_halo* halo, const double* d_owned, size_t ld, int ncols, double* d_ghost, size_t ldg);
+int     l3k_halo_export_add(l3k_halo* halo, const double* d_ghost, size_t ldg, int ncols, double* d_owned, size_t ld);
+int     l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* halo, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols,
+                          double alpha, double beta);
+
 /* ---- host-side synthetic mesh + block partition --------------------------------------------------------------------
  * Stand-in for makeCubeMesh + convertMeshToOrder + partitionMesh + the ownership / import-export context
  * (mesh/primitives/CubeMesh.hpp:16-138, mesh/ConvertMeshToOrder.hpp:51-104, mesh/PartitionMesh.hpp:142-183,

@@ -7,6 +7,9 @@
 //       .diagAndRhs(...)            ~ endAssembly() -> computeDiagAndRhs                   :877-941
 //       .assembleLocal(...)         ~ assembleLocalSystem                                  algsys/AssembleLocalSystem.hpp:234-256
 //       .assembleProblem(bnd)       ~ assembleProblem(boundary kernel, boundary_ids)      algsys/MatrixFreeSystem.hpp:58-68
+//       .apply(halo, X, Y, ...)     ~ applyImpl of a partitioned system, exchange included    :1020-1140
+//       .scatterLocalSystems(...)   ~ scatterLocalSystem / assembleGlobalSystem             algsys/ScatterLocalSystem.hpp:24-54
+//   l3k::Halo                    ~ comm::ImportExportContext + comm::Import / comm::Export  comm/ImportExport.hpp:29-72,130-215
 //   l3k::BoundaryTerm            ~ a BoundaryEquationKernel on a set of boundary views   algsys/EvaluateLocalOperator.hpp:238-330
 //   l3k::computeIntegral / computeNormL2 ~ post/Integral.hpp:113-128, post/NormL2.hpp:31-62 (one rank)
 // Errors: the reference throws std::runtime_error from util::throwingAssert (util/Assertion.hpp:88-95); so does this
@@ -47,6 +50,9 @@ public:
     Context& operator=(const Context&) = delete;
     ~Context() { l3k_ctx_destroy(m_ctx); }
     void     setStream(void* hip_stream) { check(l3k_ctx_set_stream(m_ctx, hip_stream)); }
+    // bitwise-reproducible element launches for the meshes created from now on (the reference's relaxed atomics,
+    // algsys/MatrixFreeSystem.hpp:513, are not reproducible run to run)
+    void     setDeterministic(bool on = true) { check(l3k_ctx_set_deterministic(m_ctx, on ? 1 : 0)); }
     void     synchronize() { check(l3k_ctx_synchronize(m_ctx)); }
     l3k_ctx* get() const { return m_ctx; }
 
@@ -129,6 +135,43 @@ private:
     l3k_ctx*  m_ctx{};
     int64_t   m_owned{};
     int       m_dpn{};
+};
+
+// One rank's ghost exchange (ImportExportContext + Import / Export, comm/ImportExport.hpp:29-72,130-215) carried by RCCL
+// inside the library.  uniqueId(): 128 bytes drawn by one rank and handed to the others by the host's own means (the
+// reference has MPI_Bcast); the constructor is collective over the `world` ranks.
+class Halo
+{
+public:
+    static std::array< char, 128 > uniqueId()
+    {
+        std::array< char, 128 > id{};
+        check(l3k_halo_unique_id(id.data()));
+        return id;
+    }
+    Halo(Context& ctx, const CubeMesh& mesh, int dofs_per_node, const std::array< char, 128 >& unique_id, int rank, int world)
+    {
+        const auto& v = mesh.view();
+        check(l3k_halo_create(ctx.get(), unique_id.data(), rank, world, dofs_per_node, v.n_nbrs, v.nbr_rank, v.send_offsets,
+                              v.send_nodes, v.ghost_offsets, &m_halo));
+    }
+    Halo(const Halo&)            = delete;
+    Halo& operator=(const Halo&) = delete;
+    ~Halo() { l3k_halo_destroy(m_halo); }
+    int64_t nGhostDofs() const { return l3k_halo_n_ghost_dofs(m_halo); }
+    // comm::Import: ghost rows <- owners' rows; comm::Export: owners' rows += ghost rows
+    void importGhosts(const double* d_owned, size_t ld, int ncols, double* d_ghost, size_t ldg) const
+    {
+        check(l3k_halo_import(m_halo, d_owned, ld, ncols, d_ghost, ldg));
+    }
+    void exportAdd(const double* d_ghost, size_t ldg, int ncols, double* d_owned, size_t ld) const
+    {
+        check(l3k_halo_export_add(m_halo, d_ghost, ldg, ncols, d_owned, ld));
+    }
+    l3k_halo* get() const { return m_halo; }
+
+private:
+    l3k_halo* m_halo{};
 };
 
 // A boundary equation kernel on a list of element sides (the reference's assembleProblem(kernel, boundary_ids))
@@ -221,6 +264,24 @@ public:
     void apply(const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols = 1, double alpha = 1., double beta = 0.) const
     {
         check(l3k_mf_apply(m_mf, d_x, ldx, d_y, ldy, ncols, alpha, beta));
+    }
+    // the same on the owned rows of a partitioned system: import || interior elements, border elements, export || interior
+    // elements, unpack-add, Dirichlet rows (MatrixFreeSystem::applyImpl :1020-1140), the exchange through `halo`
+    void apply(const Halo& halo, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols = 1, double alpha = 1.,
+               double beta = 0.) const
+    {
+        check(l3k_mf_apply_dist(m_mf, halo.get(), d_x, ldx, d_y, ldy, ncols, alpha, beta));
+    }
+    // scatterLocalSystem for the batch [first, first + count) of assembleLocal's output into the CSR values of the caller's
+    // graph and the global right-hand sides (algsys/ScatterLocalSystem.hpp:24-54); returns the number of entries outside
+    // the graph (skipped, as sumIntoLocalValues does)
+    int64_t scatterLocalSystems(int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
+                                const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr, bool skip_dirichlet = false) const
+    {
+        int64_t missing = 0;
+        check(l3k_assembled_scatter(m_mf, first, count, d_K, d_F, d_row_ptr, d_col_ind, d_values, d_rhs, ldr, skip_dirichlet ? 1 : 0,
+                                    &missing));
+        return missing;
     }
     // diag(A) and rhs with Dirichlet lifting; the caller zeroes d_diag / d_rhs first (computeDiagAndRhs :921-923)
     void diagAndRhs(const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs, size_t ldr) const

@@ -85,6 +85,14 @@ SIGNATURES = {
     "l3k_mf_diag_rhs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, C.c_int]),
     "l3k_mf_dirichlet_finalize": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
     "l3k_local_assemble": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "l3k_halo_unique_id": (C.c_int, [C.c_char_p]),
+    "l3k_halo_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int64_p, c_int32_p, c_int64_p,
+                                  C.POINTER(_vp)]),
+    "l3k_halo_destroy": (C.c_int, [_vp]),
+    "l3k_halo_n_ghost_dofs": (C.c_int64, [_vp]),
+    "l3k_halo_import": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t]),
+    "l3k_halo_export_add": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t]),
+    "l3k_mf_apply_dist": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double, C.c_double]),
     "l3k_assembled_scatter": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int,
                                         c_int64_p]),
     "l3k_bnd_create": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), c_int_p, C.c_int, C.c_int64,

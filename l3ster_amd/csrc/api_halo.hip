@@ -1,0 +1,372 @@
+// api_halo.hip -- the ghost exchange of a partitioned system behind the C ABI: RCCL neighbour send / receive over xGMI on a
+// stream of its own, overlapped with the interior element launches.
+//
+// Reference: comm::Import / comm::Export (comm/ImportExport.hpp:130-215: owner -> sharer copy, sharer -> owner add, one
+// message per neighbour and direction, :295-372, :402-470) and the schedule of MatrixFreeSystem::applyImpl
+// (algsys/MatrixFreeSystem.hpp:1020-1140: scale, post import, interior elements, border elements, export, Dirichlet rows).
+// The reference goes through MPI on host memory; here a C++ host hands over device pointers and the library issues
+//   ncclGroupStart; ncclSend / ncclRecv per neighbour; ncclGroupEnd
+// itself ("the multi-GPU variant takes a communicator handle and does the RCCL exchange internally").
+// RCCL is loaded at run time (dlopen librccl.so.1): a process that never creates a halo does not need it, and a process
+// that also runs torch.distributed shares torch's copy (same SONAME).
+#include "objects.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace
+{
+struct Rccl
+{
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId)    getUniqueId    = nullptr;
+    decltype(&ncclCommInitRank)   commInitRank   = nullptr;
+    decltype(&ncclCommDestroy)    commDestroy    = nullptr;
+    decltype(&ncclGroupStart)     groupStart     = nullptr;
+    decltype(&ncclGroupEnd)       groupEnd       = nullptr;
+    decltype(&ncclSend)           send           = nullptr;
+    decltype(&ncclRecv)           recv           = nullptr;
+    decltype(&ncclGetErrorString) getErrorString = nullptr;
+};
+const Rccl* rccl()
+{
+    static Rccl       r;
+    static std::mutex mtx;
+    std::lock_guard   lock{mtx};
+    if (r.lib)
+        return &r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!r.lib)
+    {
+        setError("cannot load RCCL (librccl.so.1): %s", dlerror());
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](auto& fn, const char* name) {
+        fn = reinterpret_cast< std::remove_reference_t< decltype(fn) > >(dlsym(r.lib, name));
+        ok = ok && fn != nullptr;
+    };
+    sym(r.getUniqueId, "ncclGetUniqueId");
+    sym(r.commInitRank, "ncclCommInitRank");
+    sym(r.commDestroy, "ncclCommDestroy");
+    sym(r.groupStart, "ncclGroupStart");
+    sym(r.groupEnd, "ncclGroupEnd");
+    sym(r.send, "ncclSend");
+    sym(r.recv, "ncclRecv");
+    sym(r.getErrorString, "ncclGetErrorString");
+    if (!ok)
+    {
+        setError("librccl.so.1 lacks an expected symbol");
+        dlclose(r.lib);
+        r.lib = nullptr;
+        return nullptr;
+    }
+    return &r;
+}
+#define L3K_NCCL(R, call)                                                                                              \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const ncclResult_t res_ = (call);                                                                              \
+        if (res_ != ncclSuccess)                                                                                       \
+        {                                                                                                              \
+            setError("%s failed: %s", #call, (R)->getErrorString(res_));                                               \
+            return -3;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+} // namespace
+
+// one rank's exchange lists (ImportExportContext, comm/ImportExport.hpp:29-72) + communicator, stream, events, buffers
+struct l3k_halo
+{
+    l3k_ctx*    ctx;
+    const Rccl* r;
+    ncclComm_t  comm = nullptr;
+    int         rank, world, dpn;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t  ev_main = nullptr, ev_import = nullptr, ev_export = nullptr;
+    struct Nbr
+    {
+        int                rank;
+        int64_t            n_send = 0; // dof rows this rank owns and the neighbour reads (import send / export receive)
+        DevBuf< int32_t >  send_rows;
+        int64_t            send_off = 0;   // position of this neighbour's block in the packed buffers (in rows)
+        int64_t            g0 = 0, g1 = 0; // ghost dof range owned by the neighbour (import receive / export send)
+    };
+    std::vector< Nbr > nbrs;
+    int64_t            n_ghost_dofs = 0, n_send_total = 0;
+    DevBuf< double >   xg, yg, sendbuf, recvbuf; // [cols][n_ghost_dofs], [cols][...] per neighbour block
+    int                cols = 0;
+    ~l3k_halo()
+    {
+        if (comm && r)
+            (void)r->commDestroy(comm);
+        if (ev_main)
+            (void)hipEventDestroy(ev_main);
+        if (ev_import)
+            (void)hipEventDestroy(ev_import);
+        if (ev_export)
+            (void)hipEventDestroy(ev_export);
+        if (comm_stream)
+            (void)hipStreamDestroy(comm_stream);
+    }
+};
+
+namespace
+{
+int ensureBuffers(l3k_halo* h, int ncols)
+{
+    if (ncols <= h->cols)
+        return 0;
+    const auto grow = [&](DevBuf< double >& b, int64_t rows) {
+        b = DevBuf< double >{};
+        return b.alloc(size_t(std::max< int64_t >(rows, 1)) * ncols);
+    };
+    if (int rc = grow(h->xg, h->n_ghost_dofs))
+        return rc;
+    if (int rc = grow(h->yg, h->n_ghost_dofs))
+        return rc;
+    if (int rc = grow(h->sendbuf, h->n_send_total))
+        return rc;
+    if (int rc = grow(h->recvbuf, h->n_send_total))
+        return rc;
+    h->cols = ncols;
+    return 0;
+}
+// owner -> sharer: the packed owned rows go out, the ghost slabs come in.  Issued on the communication stream behind
+// `after` (an event of the main stream); `done` is recorded behind the group.
+int postImport(l3k_halo* h, int ncols, double* ghost, size_t ldg, hipEvent_t after, hipEvent_t done)
+{
+    L3K_HIP(hipStreamWaitEvent(h->comm_stream, after, 0));
+    L3K_NCCL(h->r, h->r->groupStart());
+    for (const auto& nb : h->nbrs)
+        for (int c = 0; c < ncols; ++c)
+        {
+            if (nb.n_send > 0) // block of neighbour nb: [ncols][n_send]
+                L3K_NCCL(h->r, h->r->send(h->sendbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), ncclDouble, nb.rank,
+                                          h->comm, h->comm_stream));
+            if (nb.g1 > nb.g0)
+                L3K_NCCL(h->r, h->r->recv(ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), ncclDouble, nb.rank, h->comm, h->comm_stream));
+        }
+    L3K_NCCL(h->r, h->r->groupEnd());
+    L3K_HIP(hipEventRecord(done, h->comm_stream));
+    return 0;
+}
+// sharer -> owner: the ghost slabs go out, the packed contributions to the owned rows come in
+int postExport(l3k_halo* h, int ncols, const double* ghost, size_t ldg, hipEvent_t after, hipEvent_t done)
+{
+    L3K_HIP(hipStreamWaitEvent(h->comm_stream, after, 0));
+    L3K_NCCL(h->r, h->r->groupStart());
+    for (const auto& nb : h->nbrs)
+        for (int c = 0; c < ncols; ++c)
+        {
+            if (nb.g1 > nb.g0)
+                L3K_NCCL(h->r, h->r->send(ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), ncclDouble, nb.rank, h->comm, h->comm_stream));
+            if (nb.n_send > 0)
+                L3K_NCCL(h->r, h->r->recv(h->recvbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), ncclDouble, nb.rank,
+                                          h->comm, h->comm_stream));
+        }
+    L3K_NCCL(h->r, h->r->groupEnd());
+    L3K_HIP(hipEventRecord(done, h->comm_stream));
+    return 0;
+}
+int packAll(l3k_halo* h, const double* d_owned, size_t ld, int ncols)
+{
+    for (const auto& nb : h->nbrs)
+        if (nb.n_send > 0)
+            if (int rc = l3k_pack_rows(h->ctx, d_owned, ld, ncols, nb.send_rows.ptr, nb.n_send, h->sendbuf.ptr + nb.send_off * ncols))
+                return rc;
+    return 0;
+}
+int unpackAll(l3k_halo* h, double* d_owned, size_t ld, int ncols)
+{
+    // one launch per neighbour, in the order of the neighbour list: rows shared with several neighbours receive their
+    // contributions in a fixed order (comm/ImportExport.hpp:448-470 adds them as the messages arrive)
+    for (const auto& nb : h->nbrs)
+        if (nb.n_send > 0)
+            if (int rc = l3k_unpack_add_rows(h->ctx, h->recvbuf.ptr + nb.send_off * ncols, nb.n_send, nb.send_rows.ptr, d_owned, ld, ncols))
+                return rc;
+    return 0;
+}
+} // namespace
+
+extern "C" {
+int l3k_halo_unique_id(char* id128)
+{
+    const Rccl* r = rccl();
+    if (!r || !id128)
+    {
+        if (r)
+            setError("l3k_halo_unique_id: null argument");
+        return -1;
+    }
+    ncclUniqueId id;
+    L3K_NCCL(r, r->getUniqueId(&id));
+    static_assert(sizeof id == 128);
+    __builtin_memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+int l3k_halo_create(l3k_ctx* ctx, const char* id128, int rank, int world, int dofs_per_node, int n_nbrs, const int* nbr_rank,
+                    const int64_t* send_offsets, const int32_t* send_nodes, const int64_t* ghost_offsets, l3k_halo** out)
+{
+    if (!ctx || !id128 || !out || rank < 0 || rank >= world || dofs_per_node < 1 || n_nbrs < 0 ||
+        (n_nbrs > 0 && (!nbr_rank || !send_offsets || !ghost_offsets)))
+    {
+        setError("l3k_halo_create: inconsistent arguments");
+        return -1;
+    }
+    const Rccl* r = rccl();
+    if (!r)
+        return -3;
+    L3K_HIP(hipSetDevice(ctx->device));
+    auto h   = std::make_unique< l3k_halo >();
+    h->ctx   = ctx;
+    h->r     = r;
+    h->rank  = rank;
+    h->world = world;
+    h->dpn   = dofs_per_node;
+    for (int i = 0; i < n_nbrs; ++i)
+    {
+        if (nbr_rank[i] < 0 || nbr_rank[i] >= world)
+        {
+            setError("neighbour rank %d outside [0,%d)", nbr_rank[i], world);
+            return -1;
+        }
+        l3k_halo::Nbr nb;
+        nb.rank               = nbr_rank[i];
+        const int64_t n_nodes = send_offsets[i + 1] - send_offsets[i];
+        nb.n_send             = n_nodes * dofs_per_node;
+        nb.send_off           = h->n_send_total;
+        if (n_nodes > 0)
+        {
+            if (!send_nodes)
+            {
+                setError("l3k_halo_create: send_nodes is null");
+                return -1;
+            }
+            std::vector< int32_t > rows(static_cast< size_t >(nb.n_send));
+            for (int64_t k = 0; k < n_nodes; ++k)
+                for (int u = 0; u < dofs_per_node; ++u)
+                    rows[k * dofs_per_node + u] = send_nodes[send_offsets[i] + k] * dofs_per_node + u;
+            if (int rc = nb.send_rows.upload(rows.data(), rows.size(), ctx->stream))
+                return rc;
+            L3K_HIP(hipStreamSynchronize(ctx->stream)); // (rows is a local)
+        }
+        nb.g0 = ghost_offsets[i] * dofs_per_node;
+        nb.g1 = ghost_offsets[i + 1] * dofs_per_node;
+        h->n_send_total += nb.n_send;
+        h->n_ghost_dofs = std::max(h->n_ghost_dofs, nb.g1);
+        h->nbrs.push_back(std::move(nb));
+    }
+    ncclUniqueId id;
+    __builtin_memcpy(&id, id128, sizeof id);
+    L3K_NCCL(r, r->commInitRank(&h->comm, world, id, rank));
+    L3K_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    L3K_HIP(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    L3K_HIP(hipEventCreateWithFlags(&h->ev_import, hipEventDisableTiming));
+    L3K_HIP(hipEventCreateWithFlags(&h->ev_export, hipEventDisableTiming));
+    *out = h.release();
+    return 0;
+}
+int l3k_halo_destroy(l3k_halo* halo)
+{
+    delete halo;
+    return 0;
+}
+int64_t l3k_halo_n_ghost_dofs(const l3k_halo* halo)
+{
+    return halo ? halo->n_ghost_dofs : -1;
+}
+
+// comm::Import of a multivector over the owned rows (comm/ImportExport.hpp:295-372)
+int l3k_halo_import(l3k_halo* h, const double* d_owned, size_t ld, int ncols, double* d_ghost, size_t ldg)
+{
+    if (!h || !d_owned || !d_ghost || ncols < 1)
+    {
+        setError("l3k_halo_import: bad argument");
+        return -1;
+    }
+    L3K_HIP(hipSetDevice(h->ctx->device));
+    if (int rc = ensureBuffers(h, ncols))
+        return rc;
+    if (int rc = packAll(h, d_owned, ld, ncols))
+        return rc;
+    L3K_HIP(hipEventRecord(h->ev_main, h->ctx->stream));
+    if (int rc = postImport(h, ncols, d_ghost, ldg, h->ev_main, h->ev_import))
+        return rc;
+    L3K_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_import, 0));
+    return 0;
+}
+// comm::Export: every ghost row added into its owner's row (comm/ImportExport.hpp:402-470)
+int l3k_halo_export_add(l3k_halo* h, const double* d_ghost, size_t ldg, int ncols, double* d_owned, size_t ld)
+{
+    if (!h || !d_owned || !d_ghost || ncols < 1)
+    {
+        setError("l3k_halo_export_add: bad argument");
+        return -1;
+    }
+    L3K_HIP(hipSetDevice(h->ctx->device));
+    if (int rc = ensureBuffers(h, ncols))
+        return rc;
+    L3K_HIP(hipEventRecord(h->ev_main, h->ctx->stream));
+    if (int rc = postExport(h, ncols, d_ghost, ldg, h->ev_main, h->ev_export))
+        return rc;
+    L3K_HIP(hipStreamWaitEvent(h->ctx->stream, h->ev_export, 0));
+    return unpackAll(h, d_owned, ld, ncols);
+}
+
+// y <- alpha A x + beta y on the owned rows of a partitioned system: MatrixFreeSystem::applyImpl
+// (algsys/MatrixFreeSystem.hpp:1020-1140) with both exchanges hidden behind interior element launches
+int l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* h, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha,
+                      double beta)
+{
+    if (!mf || !h || !d_x || !d_y || ncols < 1)
+    {
+        setError("l3k_mf_apply_dist: bad argument");
+        return -1;
+    }
+    if (h->n_ghost_dofs != mf->mesh->n_ghost_nodes * mf->mesh->dofs_per_node || h->dpn != mf->mesh->dofs_per_node)
+    {
+        setError("l3k_mf_apply_dist: the halo's ghost range (%lld dofs) does not match the mesh (%lld)", (long long)h->n_ghost_dofs,
+                 (long long)(mf->mesh->n_ghost_nodes * mf->mesh->dofs_per_node));
+        return -1;
+    }
+    L3K_HIP(hipSetDevice(h->ctx->device));
+    if (int rc = ensureBuffers(h, ncols))
+        return rc;
+    hipStream_t  s   = mf->ctx->stream;
+    const size_t ldg = size_t(std::max< int64_t >(h->n_ghost_dofs, 1));
+    double *     xg = h->xg.ptr, *yg = h->yg.ptr;
+    if (int rc = l3k_mf_scale(mf, d_y, ldy, ncols, beta)) // (:1038)
+        return rc;
+    L3K_HIP(hipMemsetAsync(yg, 0, sizeof(double) * ldg * ncols, s)); // export buffer <- 0 (:1048)
+    // ---- import: pack, post; the first half of the interior elements runs meanwhile (:1055, :1073-1105)
+    if (int rc = packAll(h, d_x, ldx, ncols))
+        return rc;
+    L3K_HIP(hipEventRecord(h->ev_main, s));
+    if (int rc = postImport(h, ncols, xg, ldg, h->ev_main, h->ev_import))
+        return rc;
+    if (int rc = l3k_mf_apply_elems(mf, 3, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha, beta))
+        return rc;
+    // ---- border elements read the imported ghosts and add into the export buffer (:1058-1072)
+    L3K_HIP(hipStreamWaitEvent(s, h->ev_import, 0));
+    if (int rc = l3k_mf_apply_elems(mf, 1, d_x, ldx, xg, ldg, d_y, ldy, yg, ldg, ncols, alpha, beta))
+        return rc;
+    // ---- export: post; the second half of the interior elements runs meanwhile (:1071, ImportExport.hpp:402-433)
+    L3K_HIP(hipEventRecord(h->ev_main, s));
+    if (int rc = postExport(h, ncols, yg, ldg, h->ev_main, h->ev_export))
+        return rc;
+    if (int rc = l3k_mf_apply_elems(mf, 4, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha, beta))
+        return rc;
+    L3K_HIP(hipStreamWaitEvent(s, h->ev_export, 0));
+    if (int rc = unpackAll(h, d_y, ldy, ncols)) // (:1107, ImportExport.hpp:448-470)
+        return rc;
+    return l3k_mf_dirichlet_rows(mf, d_x, ldx, d_y, ldy, ncols, alpha); // (:1087-1098)
+}
+} // extern "C"

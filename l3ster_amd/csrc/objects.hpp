@@ -56,6 +56,24 @@ struct DevBuf
     DevBuf()   = default;
     DevBuf(const DevBuf&)            = delete;
     DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ptr{o.ptr}, n{o.n}
+    {
+        o.ptr = nullptr;
+        o.n   = 0;
+    }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o)
+        {
+            if (ptr)
+                (void)hipFree(ptr);
+            ptr   = o.ptr;
+            n     = o.n;
+            o.ptr = nullptr;
+            o.n   = 0;
+        }
+        return *this;
+    }
     ~DevBuf()
     {
         if (ptr)

@@ -182,3 +182,73 @@ class DistributedOperator:
         diag, rhs = both_o[0].contiguous(), both_o[1:].contiguous()
         be.dirichlet_finalize(dirichlet_vals_owned, diag, rhs)
         return diag, rhs
+
+
+class NativeHalo:
+    """The exchange lists of one rank handed to the library, which runs the neighbour exchange itself through RCCL on a
+    stream of its own (l3k_halo_*, include/l3k.h): what a C++ host of the reference would use instead of its MPI
+    Import / Export.  unique_id: the 128 bytes of l3k_halo_unique_id from one rank (None: rank 0 draws it and it is
+    broadcast over torch.distributed, which must then be initialised when world > 1)."""
+
+    def __init__(self, ctx, part, dofs_per_node, rank=0, world=1, unique_id=None, group=None):
+        import ctypes as C
+        from . import capi
+        lib = capi.load()
+        if unique_id is None:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                capi.check(lib.l3k_halo_unique_id(buf))
+            if world > 1:
+                dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+                t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+                dist.broadcast(t, 0, group=group)
+                buf = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+            unique_id = buf.raw
+        nn = len(part.nbr_rank)
+        so = np.concatenate([[0], np.cumsum([len(x) for x in part.send_nodes])]).astype(np.int64)
+        sn = np.concatenate([np.asarray(x, np.int32) for x in part.send_nodes]) if nn else np.zeros(0, np.int32)
+        go = np.array([part.ghost_ranges[0][0]] + [g1 for _, g1 in part.ghost_ranges], dtype=np.int64) if nn else np.zeros(1, np.int64)
+        for (g0, _), prev in zip(part.ghost_ranges[1:], part.ghost_ranges[:-1]):
+            if g0 != prev[1]:
+                raise ValueError("ghost ranges must be contiguous in neighbour order")
+        nr = np.asarray(part.nbr_rank, dtype=np.int32)
+        self._h = C.c_void_p()
+        capi.check(lib.l3k_halo_create(ctx._h, unique_id, rank, world, dofs_per_node, nn, nr.ctypes.data_as(capi.c_int_p),
+                                       so.ctypes.data_as(capi.c_int64_p), sn.ctypes.data_as(capi.c_int32_p),
+                                       go.ctypes.data_as(capi.c_int64_p), C.byref(self._h)))
+        self.ctx = ctx
+
+    def __del__(self):
+        from . import capi
+        if getattr(self, "_h", None) and capi is not None:
+            capi.load().l3k_halo_destroy(self._h)
+            self._h = None
+
+
+class NativeDistributedOperator:
+    """y <- alpha A x + beta y of a partitioned system with the exchange inside the library (l3k_mf_apply_dist)."""
+
+    def __init__(self, mf, halo):
+        self.mf, self.halo = mf, halo
+
+    def apply(self, X, Y, alpha=1.0, beta=0.0):
+        import ctypes as C
+        from . import capi
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        capi.check(capi.load().l3k_mf_apply_dist(self.mf._h, self.halo._h, vp(X), X.stride(0), vp(Y), Y.stride(0), X.shape[0], alpha, beta))
+        return Y
+
+    def import_ghosts(self, V):
+        import ctypes as C
+        from . import capi
+        lib = capi.load()
+        ng = max(int(lib.l3k_halo_n_ghost_dofs(self.halo._h)), 1)
+        ghost = torch.zeros((V.shape[0], ng), dtype=torch.float64, device=V.device)
+        capi.check(lib.l3k_halo_import(self.halo._h, C.c_void_p(V.data_ptr()), V.stride(0), V.shape[0], C.c_void_p(ghost.data_ptr()), ng))
+        return ghost
+
+    def export_add(self, ghost, owned):
+        import ctypes as C
+        from . import capi
+        capi.check(capi.load().l3k_halo_export_add(self.halo._h, C.c_void_p(ghost.data_ptr()), ghost.stride(0), owned.shape[0],
+                                                   C.c_void_p(owned.data_ptr()), owned.stride(0)))

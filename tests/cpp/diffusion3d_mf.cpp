@@ -220,6 +220,48 @@ int main()
         std::printf("results file round trip: %s\n", same ? "ok" : "MISMATCH");
         failures += !same;
     }
+    { // partitioned apply through the library's RCCL halo (l3k::Halo): a world of one rank without neighbours runs the whole
+      // schedule (scale, pack, import || interior, border, export || interior, unpack, Dirichlet rows) and must equal the
+      // plain apply; deterministic mode gives the same numbers to rounding, twice bitwise the same
+        constexpr int         p = 4, U = 4;
+        l3k::CubeMesh         mesh{{4, 3, 3}, p, {1, 1, 1}, 0, 0.1};
+        const int             unknown0[] = {0};
+        const auto            mask = mesh.dirichletMask(U, unknown0);
+        l3k::DeviceMesh       dmesh{ctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+        l3k::Halo             halo{ctx, mesh, U, l3k::Halo::uniqueId(), 0, 1};
+        const size_t          n = size_t(dmesh.nOwnedDofs());
+        std::vector< double > x(n);
+        for (auto& v : x)
+            v = dist(prng);
+        DevVec dx{n}, dy{n}, dz{n};
+        dx.up(x);
+        sys.apply(dx.p, n, dy.p, n, 1, 1.5, 0.);
+        sys.apply(halo, dx.p, n, dz.p, n, 1, 1.5, 0.);
+        ctx.synchronize();
+        const auto y = dy.down(), z = dz.down();
+        double     err = 0., nrm = 0.;
+        for (size_t i = 0; i < n; ++i)
+            err += (y[i] - z[i]) * (y[i] - z[i]), nrm += y[i] * y[i];
+        std::printf("partitioned apply (one rank, RCCL communicator of size 1): |dy| / |y| = %.3e, %lld ghost dofs\n", std::sqrt(err / nrm),
+                    (long long)halo.nGhostDofs());
+        failures += !(std::sqrt(err / nrm) < 1e-13);
+        l3k::Context dctx{0};
+        dctx.setDeterministic();
+        l3k::DeviceMesh       dmesh2{dctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys2{dmesh2, L3K_KERNEL_DIFFUSION3D, params};
+        DevVec                d1{n}, d2{n};
+        sys2.apply(dx.p, n, d1.p, n, 1, 1.5, 0.);
+        sys2.apply(dx.p, n, d2.p, n, 1, 1.5, 0.);
+        dctx.synchronize();
+        const auto a1 = d1.down(), a2 = d2.down();
+        bool       same = true;
+        double     e2 = 0.;
+        for (size_t i = 0; i < n; ++i)
+            same = same && a1[i] == a2[i], e2 += (a1[i] - y[i]) * (a1[i] - y[i]);
+        std::printf("deterministic mode: two applies bitwise %s, vs atomic mode %.3e\n", same ? "equal" : "DIFFERENT", std::sqrt(e2 / nrm));
+        failures += !(same && std::sqrt(e2 / nrm) < 1e-13);
+    }
     try
     { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)
         l3k::CubeMesh         mesh{{1, 1, 1}, 2};

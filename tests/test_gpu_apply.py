@@ -361,3 +361,19 @@ def test_partitioned_apply_through_rccl_on_one_gpu():
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RCCL partitioned apply ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [6, 2])
+def test_native_rccl_halo_self_exchange(order):
+    """l3k_halo_* / l3k_mf_apply_dist (the RCCL neighbour exchange inside the library, behind the C ABI): a one-rank cube
+    made periodic in x through the ghost machinery, import and export as ncclSend / ncclRecv of the rank to itself; against
+    the oracle on the periodic mesh and against the Python-side schedule (see the script's docstring)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_native_halo_periodic.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, script, "--order", str(order)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "native halo ok" in r.stdout, r.stdout + r.stderr
