@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from l3ster_amd import system  # noqa: E402
-from l3ster_amd.distributed import DistributedOperator, HaloPlan  # noqa: E402
+from l3ster_amd.distributed import DistributedOperator, HaloPlan, NativeDistributedOperator, NativeHalo  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
@@ -142,22 +142,39 @@ def main():
     n_owned = part.n_owned_nodes * U
     X = system.synthetic_vector_torch(part.node_grid_id[:part.n_owned_nodes], U, dev)
     Y = torch.empty_like(X)
-    op = DistributedOperator(mf, HaloPlan(part, U, dev)) if use_dist else None
+    op, native = None, False
+    if use_dist:
+        # the exchange runs inside the library (l3k_mf_apply_dist: RCCL send / receive on its own stream, behind the C ABI);
+        # L3K_BENCH_TRANSPORT=torch, or a failed communicator set-up on any rank, selects the torch.distributed transport
+        ok = 0
+        if os.environ.get("L3K_BENCH_TRANSPORT", "native") == "native":
+            try:
+                op = NativeDistributedOperator(mf, NativeHalo(ctx, part, U, rank, world))
+                ok = 1
+            except Exception as exc:  # pragma: no cover
+                print(f"[bench rank {rank}] native halo unavailable ({exc}); torch.distributed transport", file=sys.stderr, flush=True)
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        native = bool(agree.item())
+        if not native:
+            op = DistributedOperator(mf, HaloPlan(part, U, dev))
     t_setup = time.perf_counter() - t_setup
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    n_launches = 3 if op is not None else 1  # partitioned: first interior half, border elements, second interior half
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)] for _ in range(args.steps)]
 
     def step(i=None):
-        if op is not None:
-            op.apply(X, Y, 1.0, 0.0, events=None if i is None else (ev0[i], ev1[i]))
+        if op is not None and native:
+            op.apply(X, Y, 1.0, 0.0)  # (timed steps: the library stamps its three element launches, timing_begin below)
+        elif op is not None:
+            op.apply(X, Y, 1.0, 0.0, events=None if i is None else ev[i])
         elif i is None:
             mf.apply(X, Y, 1.0, 0.0)
         else:  # same three launches as l3k_mf_apply, with events around the element kernel
             mf.scale(Y, 0.0)
-            ev0[i].record()
+            ev[i][0][0].record()
             mf.apply_elems(2, X, None, Y, None, 1.0, 0.0)
-            ev1[i].record()
+            ev[i][0][1].record()
             mf.dirichlet_rows(X, Y, 1.0)
 
     def barrier():
@@ -168,6 +185,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if native:
+        op.timing_begin(args.steps)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -193,11 +212,15 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "setup_s": round(t_setup, 2)},
     }
     if rank == 0:
-        # the dominant kernel launch of rank 0: all elements (one GPU) or the interior elements (partitioned), HIP events
-        # on the launch stream inside the timed region; algorithmic bytes = 17.81 B per dof of the elements it processes
-        kernel_times = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
-        ms = float(np.median(kernel_times))  # median of the timed launches
-        n_launch_elems = part.n_interior_elems // 2 if op is not None else part.n_elems  # (partitioned: the first half)
+        # the dominant kernel of rank 0, HIP events on the launch stream inside the timed region: one launch over all
+        # elements (one GPU), or the three launches of a partitioned apply (first interior half, border elements, second
+        # interior half) summed; algorithmic bytes = 17.81 B per dof of the elements they process
+        if native:
+            kernel_times = [sum(op.timing_get(i)) for i in range(args.steps)]
+        else:
+            kernel_times = [sum(a.elapsed_time(b) for a, b in e) for e in ev]
+        ms = float(np.median(kernel_times))  # median of the timed steps
+        n_launch_elems = part.n_elems
         launch_dofs = n_launch_elems * p ** 3 * U if op is not None else global_dofs
         alg_bytes = bpd * launch_dofs
         achieved = alg_bytes / (ms * 1e-3) / 1e9
@@ -206,7 +229,8 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": traffic_source,
-                              "kernel": "sumfactFastKernel" + (" (first half of the interior elements of rank 0)" if op is not None else ""),
+                              "kernel": "sumfactFastKernel" + (" (rank 0: the three element launches of the partitioned apply, summed)" if op is not None else ""),
+                              "transport": None if op is None else ("l3k_mf_apply_dist (RCCL inside the library)" if native else "torch.distributed P2P"),
                               "kernel_ms": ms, "kernel_ms_mean": float(np.mean(kernel_times)), "kernel_ms_stat": "median of the timed launches",
                               "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
                               "algorithmic_bytes_per_launch": alg_bytes,

@@ -335,6 +335,10 @@ int     l3k_halo_destroy(l3k_halo* halo);
 int64_t l3k_halo_n_ghost_dofs(const l3k_halo* halo);
 int     l3k_halo_import(l3k_halo* halo, const double* d_owned, size_t ld, int ncols, double* d_ghost, size_t ldg);
 int     l3k_halo_export_add(l3k_halo* halo, const double* d_ghost, size_t ldg, int ncols, double* d_owned, size_t ld);
+/* HIP events around the three element launches (first interior half, border elements, second interior half) of the next
+ * n_applies calls of l3k_mf_apply_dist, on the stream they run on; _get waits for that apply and returns the durations. */
+int     l3k_halo_timing_begin(l3k_halo* halo, int n_applies);
+int     l3k_halo_timing_get(l3k_halo* halo, int apply, double ms[3]);
 int     l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* halo, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols,
                           double alpha, double beta);
 

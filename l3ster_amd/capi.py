@@ -92,6 +92,8 @@ SIGNATURES = {
     "l3k_halo_n_ghost_dofs": (C.c_int64, [_vp]),
     "l3k_halo_import": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t]),
     "l3k_halo_export_add": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t]),
+    "l3k_halo_timing_begin": (C.c_int, [_vp, C.c_int]),
+    "l3k_halo_timing_get": (C.c_int, [_vp, C.c_int, c_double_p]),
     "l3k_mf_apply_dist": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double, C.c_double]),
     "l3k_assembled_scatter": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int,
                                         c_int64_p]),

@@ -102,6 +102,9 @@ struct l3k_halo
     int64_t            n_ghost_dofs = 0, n_send_total = 0;
     DevBuf< double >   xg, yg, sendbuf, recvbuf; // [cols][n_ghost_dofs], [cols][...] per neighbour block
     int                cols = 0;
+    // optional timing of the three element launches of the next applies (bench.py's roofline at N > 1): 6 events per apply
+    std::vector< hipEvent_t > timing;
+    int                       timing_cap = 0, timing_n = 0;
     ~l3k_halo()
     {
         if (comm && r)
@@ -114,6 +117,8 @@ struct l3k_halo
             (void)hipEventDestroy(ev_export);
         if (comm_stream)
             (void)hipStreamDestroy(comm_stream);
+        for (hipEvent_t e : timing)
+            (void)hipEventDestroy(e);
     }
 };
 
@@ -142,6 +147,8 @@ int ensureBuffers(l3k_halo* h, int ncols)
 // `after` (an event of the main stream); `done` is recorded behind the group.
 int postImport(l3k_halo* h, int ncols, double* ghost, size_t ldg, hipEvent_t after, hipEvent_t done)
 {
+    if (h->n_send_total == 0 && h->n_ghost_dofs == 0) // nothing to exchange (a world of one rank): no group call
+        return hipEventRecord(done, h->ctx->stream) == hipSuccess ? 0 : -3;
     L3K_HIP(hipStreamWaitEvent(h->comm_stream, after, 0));
     L3K_NCCL(h->r, h->r->groupStart());
     for (const auto& nb : h->nbrs)
@@ -160,6 +167,8 @@ int postImport(l3k_halo* h, int ncols, double* ghost, size_t ldg, hipEvent_t aft
 // sharer -> owner: the ghost slabs go out, the packed contributions to the owned rows come in
 int postExport(l3k_halo* h, int ncols, const double* ghost, size_t ldg, hipEvent_t after, hipEvent_t done)
 {
+    if (h->n_send_total == 0 && h->n_ghost_dofs == 0)
+        return hipEventRecord(done, h->ctx->stream) == hipSuccess ? 0 : -3;
     L3K_HIP(hipStreamWaitEvent(h->comm_stream, after, 0));
     L3K_NCCL(h->r, h->r->groupStart());
     for (const auto& nb : h->nbrs)
@@ -321,6 +330,45 @@ int l3k_halo_export_add(l3k_halo* h, const double* d_ghost, size_t ldg, int ncol
     return unpackAll(h, d_owned, ld, ncols);
 }
 
+// HIP events around the three element launches (first interior half, border, second interior half) of the next `n_applies`
+// calls of l3k_mf_apply_dist, on the stream they are launched on; l3k_halo_timing_get waits for the apply and returns the
+// three durations in milliseconds
+int l3k_halo_timing_begin(l3k_halo* h, int n_applies)
+{
+    if (!h || n_applies < 0)
+    {
+        setError("l3k_halo_timing_begin: bad argument");
+        return -1;
+    }
+    L3K_HIP(hipSetDevice(h->ctx->device));
+    while (int(h->timing.size()) < 6 * n_applies)
+    {
+        hipEvent_t e;
+        L3K_HIP(hipEventCreate(&e));
+        h->timing.push_back(e);
+    }
+    h->timing_cap = n_applies;
+    h->timing_n   = 0;
+    return 0;
+}
+int l3k_halo_timing_get(l3k_halo* h, int apply, double ms[3])
+{
+    if (!h || !ms || apply < 0 || apply >= h->timing_n)
+    {
+        setError("l3k_halo_timing_get: apply %d was not timed", apply);
+        return -1;
+    }
+    hipEvent_t* e = &h->timing[size_t(6) * apply];
+    L3K_HIP(hipEventSynchronize(e[5]));
+    for (int k = 0; k < 3; ++k)
+    {
+        float t = 0.f;
+        L3K_HIP(hipEventElapsedTime(&t, e[2 * k], e[2 * k + 1]));
+        ms[k] = t;
+    }
+    return 0;
+}
+
 // y <- alpha A x + beta y on the owned rows of a partitioned system: MatrixFreeSystem::applyImpl
 // (algsys/MatrixFreeSystem.hpp:1020-1140) with both exchanges hidden behind interior element launches
 int l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* h, const double* d_x, size_t ldx, double* d_y, size_t ldy, int ncols, double alpha,
@@ -352,18 +400,26 @@ int l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* h, const double* d_x, size_t ldx, do
     L3K_HIP(hipEventRecord(h->ev_main, s));
     if (int rc = postImport(h, ncols, xg, ldg, h->ev_main, h->ev_import))
         return rc;
+    hipEvent_t* tev = h->timing_n < h->timing_cap ? &h->timing[size_t(6) * h->timing_n++] : nullptr;
+    const auto  stamp = [&](int k) { return tev ? hipEventRecord(tev[k], s) : hipSuccess; };
+    L3K_HIP(stamp(0));
     if (int rc = l3k_mf_apply_elems(mf, 3, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha, beta))
         return rc;
+    L3K_HIP(stamp(1));
     // ---- border elements read the imported ghosts and add into the export buffer (:1058-1072)
     L3K_HIP(hipStreamWaitEvent(s, h->ev_import, 0));
+    L3K_HIP(stamp(2));
     if (int rc = l3k_mf_apply_elems(mf, 1, d_x, ldx, xg, ldg, d_y, ldy, yg, ldg, ncols, alpha, beta))
         return rc;
+    L3K_HIP(stamp(3));
     // ---- export: post; the second half of the interior elements runs meanwhile (:1071, ImportExport.hpp:402-433)
     L3K_HIP(hipEventRecord(h->ev_main, s));
     if (int rc = postExport(h, ncols, yg, ldg, h->ev_main, h->ev_export))
         return rc;
+    L3K_HIP(stamp(4));
     if (int rc = l3k_mf_apply_elems(mf, 4, d_x, ldx, nullptr, 0, d_y, ldy, nullptr, 0, ncols, alpha, beta))
         return rc;
+    L3K_HIP(stamp(5));
     L3K_HIP(hipStreamWaitEvent(s, h->ev_export, 0));
     if (int rc = unpackAll(h, d_y, ldy, ncols)) // (:1107, ImportExport.hpp:448-470)
         return rc;

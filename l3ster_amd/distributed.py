@@ -75,7 +75,8 @@ class DistributedOperator:
         return self._bufs[key]
 
     def apply(self, X, Y, alpha=1.0, beta=0.0, events=None, energy=None):
-        """events: optional (start, stop) torch.cuda.Event pair recorded around the interior-element launch (bench.py).
+        """events: optional three (start, stop) torch.cuda.Event pairs recorded around the element launches (first interior
+        half, border, second interior half: bench.py); a single pair times the first launch only.
         energy: the PCG's device scalar block S; if the backend can, S[1] receives this rank's share of <X, A X> from the
         element kernels (alpha = 1, beta = 0, one column) and self.energy_fused says whether it did."""
         be, plan = self.backend, self.plan
@@ -96,17 +97,22 @@ class DistributedOperator:
         for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
             recvs.append((nb, xg[:, g0:g1] if nc == 1 else stage))  # one column: straight into the ghost slab
         reqs = self.transport.post(sends, recvs)
-        if events is not None:
-            events[0].record()
+        ev = None if events is None else (events if isinstance(events[0], (tuple, list)) else [events])
+        if ev:
+            ev[0][0].record()
         be.apply_elems(3, X, None, Y, None, alpha, beta)  # first half of the interior: overlaps the import
-        if events is not None:
-            events[1].record()
+        if ev:
+            ev[0][1].record()
         self.transport.wait(reqs)
         if nc > 1:
             for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
                 xg[:, g0:g1].copy_(stage)
         # ---- border elements, then export: sharer -> owner
+        if ev and len(ev) > 1:
+            ev[1][0].record()
         be.apply_elems(1, X, xg, Y, yg, alpha, beta)
+        if ev and len(ev) > 1:
+            ev[1][1].record()
         sends, recvs = [], []
         for (nb, g0, g1), stage in zip(plan.owners, b["stage"]):
             if nc == 1:
@@ -118,7 +124,11 @@ class DistributedOperator:
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             recvs.append((nb, rbuf))
         reqs = self.transport.post(sends, recvs)
+        if ev and len(ev) > 2:
+            ev[2][0].record()
         be.apply_elems(4, X, None, Y, None, alpha, beta)  # second half of the interior: overlaps the export
+        if ev and len(ev) > 2:
+            ev[2][1].record()
         self.transport.wait(reqs)
         for (nb, idx), rbuf in zip(plan.sharers, b["recv"]):
             be.unpack_add_rows(rbuf, idx, Y)
@@ -237,6 +247,18 @@ class NativeDistributedOperator:
         vp = lambda t: C.c_void_p(t.data_ptr())
         capi.check(capi.load().l3k_mf_apply_dist(self.mf._h, self.halo._h, vp(X), X.stride(0), vp(Y), Y.stride(0), X.shape[0], alpha, beta))
         return Y
+
+    def timing_begin(self, n_applies):
+        from . import capi
+        capi.check(capi.load().l3k_halo_timing_begin(self.halo._h, n_applies))
+
+    def timing_get(self, apply):
+        """(ms of the first interior half, the border elements, the second interior half) of a timed apply"""
+        import ctypes as C
+        from . import capi
+        ms = (C.c_double * 3)()
+        capi.check(capi.load().l3k_halo_timing_get(self.halo._h, apply, ms))
+        return tuple(ms)
 
     def import_ghosts(self, V):
         import ctypes as C
