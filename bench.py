@@ -32,6 +32,9 @@ PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # executed FP64 flops per element of sumfactFastKernel<Diffusion3D> (ISA count: (fma + fmac) * 2 + mul + add, times the
 # active lanes per element): order 6: 4 460 lane-flops x 49 lanes
 FP64_FLOP_PER_ELEM = {6: 4460 * 49}
+# executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u): per workgroup 25
+# iterations of (stage 1: 2*49*112, stage 2: 2744 outputs * 15.75, stage 3: 250 threads * 20 outputs * 28) FMAs + G
+SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (25 * (2 * 49 * 112 + 2744 * 15.75 + 250 * 20 * 28) + 343 * 16 * 7)
 
 
 def algorithmic_bytes_per_dof(p, U, F=0):
@@ -241,27 +244,47 @@ def main():
                               "fp64_tflops": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12,
                               "fp64_peak_tflops": 78.6}
         if world == 1 and op is None and p == 6:
-            # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly (K_e = B^T W B on the FP64
-            # matrix cores), order 6, streaming mode (checksums instead of 15 MB per matrix); outside the timed region
+            # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly, order 6, streaming mode
+            # (checksums instead of 15 MB per matrix); outside the timed region.  Default algorithm: sum-factorised assembly
+            # (device/assemble.hpp: ~98 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
+            # the FP64 matrix cores (4 523 MFLOP per element using symmetry), the formulation the reference computes
             batch, reps = 512, 3
             apart = system.CubePartition(8, p, perturb=0.1)
             amesh = system.DeviceMesh(ctx, apart, U)
             amf = system.MatrixFreeSystem(amesh, kid, [1.0, 1.0])
-            amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            for _ in range(reps):
+
+            def assembly_rate():
                 amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
-            a1.record()
-            torch.cuda.synchronize()
-            ams = a0.elapsed_time(a1) / reps
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for _ in range(reps):
+                    amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
+                a1.record()
+                torch.cuda.synchronize()
+                return batch / (a0.elapsed_time(a1) / reps * 1e-3)
+
+            rate = assembly_rate()
+            os.environ["L3K_ASSEMBLE_DENSE"] = "1"
+            try:
+                rate_dense = assembly_rate()
+            finally:
+                os.environ.pop("L3K_ASSEMBLE_DENSE", None)
             nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * 7
-            rate = batch / (ams * 1e-3)
+            dense_flops = kd * nd * (nd + 1)          # symmetric half of 2*K*N^2
+            sf_flops = SUMFACT_ASSEMBLY_FLOP_PER_ELEM  # executed by the sum-factorised kernel (order 6, U = 4, E = 7)
             result["assembled_path"] = {"metric": "element-matrices/s for assembled path (LocalAssembly, Diffusion3D, hex p=6)",
                                         "value": rate, "unit": "element matrices/s", "batch": batch,
-                                        "roofline": {"bound": "mfma", "achieved": rate * kd * nd * (nd + 1) / 1e12, "peak": 78.6,
-                                                     "unit": "TFLOP/s", "frac": rate * kd * nd * (nd + 1) / 1e12 / 78.6,
-                                                     "flops": "symmetric half, 2*K*N*(N+1)/2 per element"}}
+                                        "algorithm": "sum-factorised assembly on index pairs (O(n^7) per pair of unknowns), FP64 vector pipe",
+                                        "roofline": {"bound": "mfma", "achieved": rate * sf_flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                                     "frac": rate * sf_flops / 1e12 / 78.6,
+                                                     "flops": "executed: 97.8 MFLOP per element; FP64 matrix and vector pipes are one pipe "
+                                                              "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)",
+                                                     "dense_equivalent_tflops": rate * dense_flops / 1e12},
+                                        "dense_mfma_kernel": {"value": rate_dense, "unit": "element matrices/s",
+                                                              "roofline": {"bound": "mfma", "achieved": rate_dense * dense_flops / 1e12,
+                                                                           "peak": 78.6, "unit": "TFLOP/s",
+                                                                           "frac": rate_dense * dense_flops / 1e12 / 78.6,
+                                                                           "flops": "symmetric half, 2*K*N*(N+1)/2 per element"}}}
             del amf, amesh, apart
             # BASELINE.json configs[1]: the same apply at order 4 on the same 64^3 mesh (outside the timed region)
             p4 = 4

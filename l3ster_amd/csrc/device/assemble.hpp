@@ -289,6 +289,258 @@ __global__ __launch_bounds__(256, L3K_GEMM_MIN_BLOCKS) void assembleGemmKernel(c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sum-factorised LocalAssembly.  The dense product above executes 2 * (nq^3 E) * (n^3 U)^2 / 2 flops per element
+// (4.5 GFLOP at order 6) on a part whose FP64 matrix rate equals its FP64 vector rate (and shares the pipe with it:
+// profiles/r02_fp64_vector_matrix_coexecution.log), so the matrix cores buy nothing and the flop count is everything.
+// With the tensor-product basis
+//     K[(b,u),(b',u')] = sum_{k,k'} sum_q G_kk'^{uu'}(q) psi_k(b,q) psi_k'(b',q),   G_kk'^{uu'}(q) = w detJ sum_e c_k[e][u] c_k'[e][u'],
+// psi_0 = Ix Iy Iz, psi_1 = Dx Iy Iz, psi_2 = Ix Dy Iz, psi_3 = Ix Iy Dz, the sum over q = (qx, qy, qz) factorises
+// direction by direction on index PAIRS (b1, b1') with the product tables P[t][(b1,b1')][q1] = T_s[b1][q1] T_s'[b1'][q1]
+// (t = s + 2 s', T_0 = I, T_1 = D):
+//     stage 1 (qx):  A[ty,tz][qy,qz]        = sum_{(k,k') of type (ty,tz)} sum_qx P[tx][(bx,bx')][qx] G_kk'[qx,qy,qz]     (9 groups)
+//     stage 2 (qy):  B[tz][(by,by')][qz]    = sum_{ty} sum_qy P[ty][(by,by')][qy] A[ty,tz][qy,qz]                          (4 groups)
+//     stage 3 (qz):  M[(by,by')][(bz,bz')]  = sum_{tz} sum_qz B[tz][(by,by')][qz] P[tz][(bz,bz')][qz]
+// for every (bx, bx') and every pair of unknowns: ~1e8 flop per element at order 6 instead of 4.5e9 (O(n^7) instead of
+// O(n^9) per pair of unknowns), the same K_e to rounding (another summation order).  One workgroup per (element, u' <= u);
+// only the blocks u' <= u are formed (diagonal blocks: b' <= b) and mirrored, so K_e is bitwise symmetric as the
+// reference's (algsys/AssembleLocalSystem.hpp:176-182).
+template < int P, int NQ >
+struct SfAsmCfg
+{
+    static constexpr int N1 = P + 1, N2 = N1 * N1, NQP = NQ * NQ * NQ;
+    static constexpr int PAIRS = 2;                       // (bx, bx') pairs per iteration
+    static constexpr int TR = 4, TC = 5;                  // outputs per thread in stage 3: TR rows x TC columns
+    static constexpr int ROWS = PAIRS * N2;               // stage-3 rows per iteration: (pair, by, by')
+    static constexpr int RT = (ROWS + TR - 1) / TR, CT = (N2 + TC - 1) / TC;
+    static constexpr int K3 = 4 * NQ;                     // stage-3 contraction length: (tz, qz)
+    static constexpr int BROW = ROWS + 1;                 // B stored [K3][BROW] (row index fastest; +1 against bank conflicts)
+    static constexpr int PZROW = CT * TC;                 // Pz stored [K3][PZROW]
+    // G | P | A | B | Pz
+    static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * NQ +
+                                                    size_t(K3) * BROW + size_t(K3) * PZROW);
+    static constexpr bool feasible = lds <= 160 * 1024 && RT * CT <= 1024;
+    static constexpr int  threads  = RT * CT <= 256 ? 256 : (RT * CT <= 512 ? 512 : 1024);
+};
+
+template < typename K, int P, int NQ >
+__global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
+                                                                                       int64_t elem0)
+{
+    constexpr KernelParams params = K::params;
+    constexpr int          U = params.n_unknowns, E = params.n_equations;
+    using C = SfAsmCfg< P, NQ >;
+    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, TR = C::TR, TC = C::TC, RT = C::RT, CT = C::CT;
+    constexpr int         K3 = C::K3, BROW = C::BROW, PZROW = C::PZROW, ROWS = C::ROWS, NT = C::threads, ND = N1 * N2 * U;
+    constexpr int         CS = coeffStride< K >();
+    constexpr TableLayout TL{N1, NQ};
+    // the 16 terms (k, k') by group: type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1)
+    constexpr auto ty_of = [](int k, int kp) { return (k == 2) + 2 * (kp == 2); };
+    constexpr auto tz_of = [](int k, int kp) { return (k == 3) + 2 * (kp == 3); };
+    // group id of (ty, tz): the 9 combinations that occur
+    constexpr auto grp = [](int ty, int tz) {
+        constexpr int g[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}};
+        return g[ty][tz];
+    };
+
+    extern __shared__ double lds[];
+    double* const            G  = lds;                       // [16][NQP]
+    double* const            Pt = G + 16 * NQP;              // [4][N2][NQ]
+    double* const            A  = Pt + 4 * N2 * NQ;          // [PAIRS][9][NQ*NQ]
+    double* const            B  = A + PAIRS * 9 * NQ * NQ;   // [K3 = (tz, qz)][BROW]: row = pair * N2 + (by + N1 by')
+    double* const            Pz = B + K3 * BROW;             // [K3][PZROW]: column = bz + N1 bz' (zero padded)
+
+    const int     tid = threadIdx.x;
+    const int64_t el  = blockIdx.y;
+    // unknown pair of this workgroup: u' <= u
+    int u = 0, rem = blockIdx.x;
+    while (rem > u)
+    {
+        rem -= u + 1;
+        ++u;
+    }
+    const int up = rem;
+
+    // ---- product tables and G
+    for (int i = tid; i < 4 * N2 * NQ; i += NT)
+    {
+        const int t = i / (N2 * NQ), r = i - t * (N2 * NQ), bb = r / NQ, q = r - bb * NQ;
+        const int b1 = bb % N1, b1p = bb / N1;
+        const double* T0 = a.tables + ((t & 1) ? TL.offD() : TL.offI());
+        const double* T1 = a.tables + ((t & 2) ? TL.offD() : TL.offI());
+        Pt[i]            = T0[b1 * NQ + q] * T1[b1p * NQ + q];
+    }
+    for (int i = tid; i < K3 * PZROW; i += NT)
+    {
+        const int k3 = i / PZROW, c = i - k3 * PZROW, tz = k3 / NQ, qz = k3 - tz * NQ;
+        double    v  = 0.;
+        if (c < N2)
+        {
+            const double* T0 = a.tables + ((tz & 1) ? TL.offD() : TL.offI());
+            const double* T1 = a.tables + ((tz & 2) ? TL.offD() : TL.offI());
+            v                = T0[(c % N1) * NQ + qz] * T1[(c / N1) * NQ + qz];
+        }
+        Pz[i] = v;
+    }
+    const double* cel = cbuf + el * NQP * CS;
+    for (int q = tid; q < NQP; q += NT)
+    {
+        const double* cq = cel + int64_t(q) * CS;
+        const double  w  = cq[CS - 1];
+        double        cu[E][4], cp[E][4];
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                cu[e][k] = cq[(e * U + u) * 4 + k];
+                cp[e][k] = cq[(e * U + up) * 4 + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp)
+            {
+                double g = 0.;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    g += cu[e][k] * cp[e][kp];
+                G[(k * 4 + kp) * NQP + q] = w * g;
+            }
+    }
+    __syncthreads();
+
+    // stage-3 tile of this thread
+    const int  rt = tid % RT, ct = tid / RT;
+    const bool tile = ct < CT;
+    double     csum = 0.;
+    double*    Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
+
+    constexpr int NPAIR = N1 * N1;
+    for (int pair0 = 0; pair0 < NPAIR; pair0 += PAIRS)
+    {
+        // ---- stage 1: A[pp][g][qy][qz]
+        for (int i = tid; i < PAIRS * 9 * NQ * NQ; i += NT)
+        {
+            const int pp = i / (9 * NQ * NQ), r = i - pp * (9 * NQ * NQ), g = r / (NQ * NQ), qyz = r - g * (NQ * NQ);
+            const int pair = pair0 + pp;
+            double    acc  = 0.;
+            if (pair < NPAIR)
+            {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp)
+                        if (grp(ty_of(k, kp), tz_of(k, kp)) == g) // (g is a run-time value: 16 compares, the group's terms add)
+                        {
+                            const int     tx = (k == 1) + 2 * (kp == 1);
+                            const double* px = Pt + (tx * N2 + pair) * NQ;
+                            const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
+#pragma unroll
+                            for (int qx = 0; qx < NQ; ++qx)
+                                acc += px[qx] * gq[qx];
+                        }
+            }
+            A[i] = acc;
+        }
+        __syncthreads();
+        // ---- stage 2: B[(tz, qz)][pp * N2 + (by, by')]
+        for (int i = tid; i < K3 * ROWS; i += NT)
+        {
+            const int k3 = i / ROWS, row = i - k3 * ROWS, tz = k3 / NQ, qz = k3 - tz * NQ, pp = row / N2, bb = row - pp * N2;
+            double    acc = 0.;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty)
+            {
+                const int g = tz == 0 ? ty : (tz == 1 ? (ty == 0 ? 4 : (ty == 2 ? 8 : -1)) : (tz == 2 ? (ty == 0 ? 5 : (ty == 1 ? 7 : -1)) : (ty == 0 ? 6 : -1)));
+                if (g >= 0)
+                {
+                    const double* py = Pt + (ty * N2 + bb) * NQ;
+                    const double* aq = A + (pp * 9 + g) * NQ * NQ + qz * NQ; // [qz][qy]: A index = qy + NQ * qz
+#pragma unroll
+                    for (int qy = 0; qy < NQ; ++qy)
+                        acc += py[qy] * aq[qy];
+                }
+            }
+            B[k3 * BROW + row] = acc;
+        }
+        __syncthreads();
+        // ---- stage 3: M[row][col] = sum_k3 B[k3][row] Pz[k3][col], TR x TC outputs per thread
+        if (tile)
+        {
+            double m[TR][TC];
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                    m[i][j] = 0.;
+#pragma unroll 4
+            for (int k3 = 0; k3 < K3; ++k3)
+            {
+                double br[TR], pc[TC];
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+                    br[i] = rt * TR + i < ROWS ? B[k3 * BROW + rt * TR + i] : 0.;
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                    pc[j] = Pz[k3 * PZROW + ct * TC + j];
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TC; ++j)
+                        m[i][j] += br[i] * pc[j];
+            }
+            // ---- output: K[(b,u),(b',u')], b = bx + N1 (by + N1 bz), b' likewise; blocks u' < u whole, u' = u lower part; mirrored
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+            {
+                const int row = rt * TR + i, pp = row / N2, bb = row - pp * N2, pair = pair0 + pp;
+                if (row >= ROWS || pair >= NPAIR)
+                    continue;
+                const int bx = pair % N1, bxp = pair / N1, by = bb % N1, byp = bb / N1;
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+                {
+                    const int col = ct * TC + j;
+                    if (col >= N2)
+                        continue;
+                    const int bz = col % N1, bzp = col / N1;
+                    const int b = bx + N1 * (by + N1 * bz), bp = bxp + N1 * (byp + N1 * bzp);
+                    if (u == up && bp > b)
+                        continue;
+                    const int    gi = b * U + u, gj = bp * U + up;
+                    const double v  = m[i][j];
+                    if (Kel)
+                    {
+                        Kel[int64_t(gi) * ND + gj] = v;
+                        if (gi != gj)
+                            Kel[int64_t(gj) * ND + gi] = v;
+                    }
+                    csum += v * (1 + ((gi * 31 + gj * 17) % 7));
+                    if (gi != gj)
+                        csum += v * (1 + ((gj * 31 + gi * 17) % 7));
+                }
+            }
+        }
+        __syncthreads(); // A and B are rewritten by the next iteration
+    }
+    if (a.checksum)
+    {
+        // fixed-order reduction over the workgroup, one atomic per workgroup
+        double* red = A; // (free after the last barrier)
+        red[tid]    = csum;
+        __syncthreads();
+        for (int w = NT / 2; w > 0; w >>= 1)
+        {
+            if (tid < w)
+                red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0)
+            unsafeAtomicAdd(a.checksum + elem0 + el, red[0]);
+    }
+}
+
 // K: batch [a.elem_begin, a.elem_begin + a.elem_count); output slot elem0 + i for the i-th element of the batch
 template < typename K, int P, int NQ >
 int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
@@ -317,8 +569,29 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     }
     double* cbuf = a.workspace; // coeffStride * nq^3 doubles per element, + 1 flag
     hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
-    hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,
-                       int64_t(a.elem_begin_out));
+    using S = SfAsmCfg< P, NQ >;
+    // the sum-factorised kernel unless it does not fit or L3K_ASSEMBLE_DENSE=1 asks for the dense MFMA product (cross-check)
+    const bool dense = !S::feasible || std::getenv("L3K_ASSEMBLE_DENSE") != nullptr;
+    if constexpr (S::feasible)
+        if (!dense)
+        {
+            auto ks = assembleSumfactKernel< K, P, NQ >;
+            static bool sf_attr = false;
+            if (!sf_attr)
+            {
+                if (hipFuncSetAttribute(reinterpret_cast< const void* >(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) != hipSuccess)
+                {
+                    setError("hipFuncSetAttribute failed for the sum-factorised assembly kernel");
+                    return -3;
+                }
+                sf_attr = true;
+            }
+            hipLaunchKernelGGL(ks, dim3(U * (U + 1) / 2, static_cast< unsigned >(a.elem_count)), dim3(S::threads), S::lds, stream, a, cbuf,
+                               int64_t(a.elem_begin_out));
+        }
+    if (dense)
+        hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,
+                           int64_t(a.elem_begin_out));
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
     {

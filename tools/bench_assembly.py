@@ -1,5 +1,5 @@
-"""Element-matrices/s of LocalAssembly (BASELINE.json config 3: Diffusion3D, hex, order 6, K_e = B^T W B on the FP64
-matrix cores).  Streaming mode: batches of elements, K_e reduced to a checksum on the device (the 64^3 mesh's matrices
+"""Element-matrices/s of LocalAssembly (BASELINE.json config 3: Diffusion3D, hex, order 6): the sum-factorised assembly
+kernel by default, the dense K_e = B^T W B product on the FP64 matrix cores with L3K_ASSEMBLE_DENSE=1.  Streaming mode: batches of elements, K_e reduced to a checksum on the device (the 64^3 mesh's matrices
 would be 3.9 TB); optionally stored.  Prints one JSON line.
     python tools/bench_assembly.py [--order 6] [--batch 64] [--steps 5] [--store]"""
 import argparse
@@ -44,7 +44,9 @@ ms = float(np.median([x.elapsed_time(y) for x, y in zip(e0, e1)]))
 nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * E
 flops_sym = 1.0 * kd * nd * (nd + 1)  # 2*kd*nd^2/2 (+diagonal): the symmetric half the reference computes (rankUpdate)
 rate = a.batch / (ms * 1e-3)
+dense = os.environ.get("L3K_ASSEMBLE_DENSE") is not None
 print(json.dumps({"metric": "element-matrices/s for assembled path (LocalAssembly, Diffusion3D, hex p=%d)" % p, "value": rate,
+                  "algorithm": "dense (W Z)^T Z on v_mfma_f64_16x16x4" if dense else "sum-factorised (the TFLOP/s below are dense-equivalent, not executed)",
                   "unit": "element matrices/s", "ms_per_batch": ms, "batch": a.batch, "stored": a.store, "dtype": "f64",
                   "roofline": {"bound": "mfma", "achieved": rate * flops_sym / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": rate * flops_sym / 1e12 / FP64_MFMA_PEAK_TFLOPS,
