@@ -3,6 +3,8 @@
 // point fails with an error.
 #include "objects.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <unordered_map>
 
 using l3k::api::KernelMeta;
@@ -186,6 +188,7 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.exclusive_node_begin = m->exclusive_begin;
     a.exclusive_node_end   = m->exclusive_end;
     a.slot_tab             = m->slot_tab.ptr;
+    a.all_affine           = m->all_affine ? 1 : 0;
     // dynamic batch distribution of the single-wave kernel (L3K_FAST_STATIC=1: the static deal)
     const bool static_deal = std::getenv("L3K_FAST_STATIC") != nullptr; // (read per launch: the tests switch it)
     a.work_counters        = static_deal ? nullptr : mf->ctx->work_counters;
@@ -773,20 +776,41 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
         }
     }
     std::vector< int64_t > rows;
-    std::vector< uint8_t > flags; // host staging buffers must outlive the stream synchronisation below
+    // per-element flags: bit 0 = the element touches a Dirichlet dof, bit 1 = its tri-linear map is affine (a
+    // parallelepiped: the bilinear and trilinear coefficient vectors of the 8 vertices vanish), so its Jacobian is one
+    // matrix -- the element kernel then inverts it once per element instead of once per quadrature point
+    std::vector< uint8_t > flags(static_cast< size_t >(d->n_elems), 0); // (host staging: outlives the synchronisation below)
+    for (int64_t e = 0; e < d->n_elems; ++e)
+    {
+        const double* v = d->elem_verts + e * 24;
+        double        scale = 0., dev = 0.;
+        for (int s = 0; s < 3; ++s)
+        {
+            auto c = [&](int sx, int sy, int sz) { // coefficient of xi^sx eta^sy zeta^sz (x 8)
+                double acc = 0.;
+                for (int k = 0; k < 8; ++k)
+                    acc += ((sx && !(k & 1)) ? -1. : 1.) * ((sy && !(k & 2)) ? -1. : 1.) * ((sz && !(k & 4)) ? -1. : 1.) * v[k * 3 + s];
+                return acc;
+            };
+            scale = std::max({scale, std::fabs(c(1, 0, 0)), std::fabs(c(0, 1, 0)), std::fabs(c(0, 0, 1))});
+            dev   = std::max({dev, std::fabs(c(1, 1, 0)), std::fabs(c(1, 0, 1)), std::fabs(c(0, 1, 1)), std::fabs(c(1, 1, 1))});
+        }
+        if (dev <= 1e-14 * scale)
+            flags[e] |= 2;
+    }
+    m->all_affine = d->n_elems > 0;
+    for (uint8_t f : flags)
+        m->all_affine = m->all_affine && (f & 2);
     if (d->dirichlet)
     {
-        flags.assign(static_cast< size_t >(d->n_elems), 0);
         for (int64_t e = 0; e < d->n_elems; ++e)
-            for (int64_t i = 0; i < N && !flags[e]; ++i)
+            for (int64_t i = 0; i < N && !(flags[e] & 1); ++i)
                 for (int k = 0; k < d->dofs_per_node; ++k)
                     if (d->dirichlet[int64_t(d->elem_nodes[e * N + i]) * d->dofs_per_node + k])
                     {
-                        flags[e] = 1;
+                        flags[e] |= 1;
                         break;
                     }
-        if (int rc = m->elem_flags.upload(flags.data(), flags.size(), ctx->stream))
-            return rc;
         if (int rc = m->dirichlet.upload(d->dirichlet, size_t(n_nodes * d->dofs_per_node), ctx->stream))
             return rc;
         for (int64_t i = 0; i < d->n_owned_nodes * d->dofs_per_node; ++i) // getOwnedDirichletDofs
@@ -795,6 +819,8 @@ int l3k_mesh_create(l3k_ctx* ctx, const l3k_mesh_desc* d, l3k_mesh** out)
         if (int rc = m->owned_dirichlet_rows.upload(rows.data(), rows.size(), ctx->stream))
             return rc;
     }
+    if (int rc = m->elem_flags.upload(flags.data(), flags.size(), ctx->stream))
+        return rc;
     if (ctx->deterministic)
         if (int rc = buildDeterministicPlan(*m, d, flags))
             return rc;

@@ -310,7 +310,7 @@ struct SfAsmCfg
 {
     static constexpr int N1 = P + 1, N2 = N1 * N1, NQP = NQ * NQ * NQ;
     static constexpr int PAIRS = 2;                       // (bx, bx') pairs per iteration
-    static constexpr int TR = 4, TC = 5;                  // outputs per thread in stage 3: TR rows x TC columns
+    static constexpr int TR = 2, TC = 5;                  // outputs per thread in stage 3: TR rows (strided by RT) x TC columns
     static constexpr int ROWS = PAIRS * N2;               // stage-3 rows per iteration: (pair, by, by')
     static constexpr int RT = (ROWS + TR - 1) / TR, CT = (N2 + TC - 1) / TC;
     static constexpr int K3 = 4 * NQ;                     // stage-3 contraction length: (tz, qz)
@@ -320,7 +320,8 @@ struct SfAsmCfg
     static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * NQ +
                                                     size_t(K3) * BROW + size_t(K3) * PZROW);
     static constexpr bool feasible = lds <= 160 * 1024 && RT * CT <= 1024;
-    static constexpr int  threads  = RT * CT <= 256 ? 256 : (RT * CT <= 512 ? 512 : 1024);
+    // two waves per SIMD hide the LDS round trips of the three stages (one workgroup per CU: G alone is 16 nq^3 doubles)
+    static constexpr int  threads  = RT * CT <= 512 ? 512 : 1024;
 };
 
 template < typename K, int P, int NQ >
@@ -334,14 +335,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     constexpr int         K3 = C::K3, BROW = C::BROW, PZROW = C::PZROW, ROWS = C::ROWS, NT = C::threads, ND = N1 * N2 * U;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
-    // the 16 terms (k, k') by group: type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1)
-    constexpr auto ty_of = [](int k, int kp) { return (k == 2) + 2 * (kp == 2); };
-    constexpr auto tz_of = [](int k, int kp) { return (k == 3) + 2 * (kp == 3); };
-    // group id of (ty, tz): the 9 combinations that occur
-    constexpr auto grp = [](int ty, int tz) {
-        constexpr int g[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}};
-        return g[ty][tz];
-    };
+    // the 16 terms (k, k') by group: type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1); groups (ty, tz):
+    // 0 (II,II)  1 (DI,II)  2 (ID,II)  3 (DD,II)  4 (II,DI)  5 (II,ID)  6 (II,DD)  7 (DI,ID)  8 (ID,DI)
 
     extern __shared__ double lds[];
     double* const            G  = lds;                       // [16][NQP]
@@ -419,29 +414,37 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     constexpr int NPAIR = N1 * N1;
     for (int pair0 = 0; pair0 < NPAIR; pair0 += PAIRS)
     {
-        // ---- stage 1: A[pp][g][qy][qz]
-        for (int i = tid; i < PAIRS * 9 * NQ * NQ; i += NT)
+        // ---- stage 1: A[pp][g][qy][qz]; the group is the slowest index of the work list, so a wave runs one group's
+        // compile-time term list
+        for (int i = tid; i < 9 * PAIRS * NQ * NQ; i += NT)
         {
-            const int pp = i / (9 * NQ * NQ), r = i - pp * (9 * NQ * NQ), g = r / (NQ * NQ), qyz = r - g * (NQ * NQ);
+            const int g = i / (PAIRS * NQ * NQ), r = i - g * (PAIRS * NQ * NQ), pp = r / (NQ * NQ), qyz = r - pp * (NQ * NQ);
             const int pair = pair0 + pp;
             double    acc  = 0.;
             if (pair < NPAIR)
             {
+                const auto term = [&](int k, int kp) {
+                    const int     tx = (k == 1) + 2 * (kp == 1);
+                    const double* px = Pt + (tx * N2 + pair) * NQ;
+                    const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int kp = 0; kp < 4; ++kp)
-                        if (grp(ty_of(k, kp), tz_of(k, kp)) == g) // (g is a run-time value: 16 compares, the group's terms add)
-                        {
-                            const int     tx = (k == 1) + 2 * (kp == 1);
-                            const double* px = Pt + (tx * N2 + pair) * NQ;
-                            const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
-#pragma unroll
-                            for (int qx = 0; qx < NQ; ++qx)
-                                acc += px[qx] * gq[qx];
-                        }
+                    for (int qx = 0; qx < NQ; ++qx)
+                        acc += px[qx] * gq[qx];
+                };
+                switch (g)
+                {
+                case 0: term(0, 0), term(0, 1), term(1, 0), term(1, 1); break; // (ty, tz) = (II, II)
+                case 1: term(2, 0), term(2, 1); break;                         // (DI, II)
+                case 2: term(0, 2), term(1, 2); break;                         // (ID, II)
+                case 3: term(2, 2); break;                                     // (DD, II)
+                case 4: term(3, 0), term(3, 1); break;                         // (II, DI)
+                case 5: term(0, 3), term(1, 3); break;                         // (II, ID)
+                case 6: term(3, 3); break;                                     // (II, DD)
+                case 7: term(2, 3); break;                                     // (DI, ID)
+                default: term(3, 2); break;                                    // (ID, DI)
+                }
             }
-            A[i] = acc;
+            A[(pp * 9 + g) * NQ * NQ + qyz] = acc;
         }
         __syncthreads();
         // ---- stage 2: B[(tz, qz)][pp * N2 + (by, by')]
@@ -479,8 +482,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
             {
                 double br[TR], pc[TC];
 #pragma unroll
-                for (int i = 0; i < TR; ++i)
-                    br[i] = rt * TR + i < ROWS ? B[k3 * BROW + rt * TR + i] : 0.;
+                for (int i = 0; i < TR; ++i) // (rows rt + RT * i: consecutive lanes read consecutive doubles)
+                    br[i] = rt + RT * i < ROWS ? B[k3 * BROW + rt + RT * i] : 0.;
 #pragma unroll
                 for (int j = 0; j < TC; ++j)
                     pc[j] = Pz[k3 * PZROW + ct * TC + j];
@@ -494,7 +497,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
 #pragma unroll
             for (int i = 0; i < TR; ++i)
             {
-                const int row = rt * TR + i, pp = row / N2, bb = row - pp * N2, pair = pair0 + pp;
+                const int row = rt + RT * i, pp = row / N2, bb = row - pp * N2, pair = pair0 + pp;
                 if (row >= ROWS || pair >= NPAIR)
                     continue;
                 const int bx = pair % N1, bxp = pair / N1, by = bb % N1, byp = bb / N1;

@@ -55,7 +55,7 @@ struct ElemArgs
     const uint32_t* elem_nodes; // [n_elems][N]
     const double*   elem_verts; // [n_elems][8][3]
     const uint8_t*  dirichlet;  // [n_local_dofs] or nullptr
-    const uint8_t*  elem_flags; // [n_elems] bit 0: element touches a Dirichlet dof (nullptr when no mask)
+    const uint8_t*  elem_flags; // [n_elems] bit 0: element touches a Dirichlet dof, bit 1: affine element (one Jacobian)
     int64_t         exclusive_node_begin, exclusive_node_end; // nodes in [begin,end) belong to exactly one element
     const double*   tables;     // TableLayout (device)
     const double*   tables_host; // the same block in host memory (copied into the kernel arguments of the fast path)
@@ -89,6 +89,7 @@ struct ElemArgs
     double* workspace; // per-QP coefficients of the batch + 1 trailing flag (degenerate element)
     int64_t elem_begin_out; // output slot of the first element of the batch
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
+    int     all_affine; // every element of the mesh is a parallelepiped (one Jacobian per element)
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
     long long* stamps; // L3K_ABLATION builds with env L3K_STAMPS: per-stage cycle counters of workgroup 0 ([iteration][16])

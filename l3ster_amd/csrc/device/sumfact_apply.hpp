@@ -143,6 +143,10 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
 // The quadrature-point stage (evalAtHexQPs, algsys/SumFactorization.hpp:707-753) for one point.
 // v[op], dv[d][op]: values / REFERENCE derivatives of the operands (op = u + U*r) and, after them, the F fields.
 // On return r0[op], rd[d][op] hold A0^T t and D_d^T t.  RHS_MODE: t = wgt * (f - B x) (rhs with Dirichlet lifting).
+template < typename K, int R, bool RHS_MODE, int RT, int C0, bool ENERGY >
+__device__ __forceinline__ void qpStageAt(const K& kern, const double (*Ji)[3], double det, const double* xyz, double w_ref, double time,
+                                          const double* v, const double (*dv)[K::params.n_unknowns * R + K::params.n_fields], double* r0,
+                                          double (*rd)[K::params.n_unknowns * R], double* energy);
 // ENERGY: *energy += sum_e wgt * (B x)_e^2, this point's share of x^T A x.
 template < typename K, int R, bool RHS_MODE, int RT = R, int C0 = 0, bool ENERGY = false >
 __device__ __forceinline__ void qpStage(const K&      kern,
@@ -156,13 +160,28 @@ __device__ __forceinline__ void qpStage(const K&      kern,
                                         double (*rd)[K::params.n_unknowns * R],
                                         double*       energy = nullptr)
 {
-    constexpr KernelParams params = K::params;
-    constexpr int          U = params.n_unknowns, E = params.n_equations, F = params.n_fields, OPS = U * R;
-    using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, RT} >; // rhs is E x RT, columns C0..C0+R-1 used
-
     double Jm[3][3], Ji[3][3], xyz[3];
     hexPointOnPencil(G, xi, Jm, xyz);
     const double det = inverse3(Jm, Ji);
+    qpStageAt< K, R, RHS_MODE, RT, C0, ENERGY >(kern, Ji, det, xyz, w_ref, time, v, dv, r0, rd, energy);
+}
+// the same with the geometry of the point given: Ji = (dx/dxi)^{-1} (Ji[d][s] = d xi_d / d x_s), det, position
+template < typename K, int R, bool RHS_MODE, int RT, int C0, bool ENERGY >
+__device__ __forceinline__ void qpStageAt(const K&      kern,
+                                          const double (*Ji)[3],
+                                          double        det,
+                                          const double* xyz,
+                                          double        w_ref,
+                                          double        time,
+                                          const double* v,
+                                          const double (*dv)[K::params.n_unknowns * R + K::params.n_fields],
+                                          double*       r0,
+                                          double (*rd)[K::params.n_unknowns * R],
+                                          double*       energy)
+{
+    constexpr KernelParams params = K::params;
+    constexpr int          U = params.n_unknowns, E = params.n_equations, F = params.n_fields, OPS = U * R;
+    using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, RT} >; // rhs is E x RT, columns C0..C0+R-1 used
     const double wgt = w_ref * det;
 
     typename Iface::DomainInput in;

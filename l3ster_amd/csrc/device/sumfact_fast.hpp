@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace l3k::dev
 {
@@ -55,12 +56,13 @@ __device__ __forceinline__ void sweepEO(const double (&in)[NIN], double (&out)[N
             A += e[r] * We[r * RO + q];
         if constexpr (ACC)
         {
-            double B = 0.;
+            // lo = A + B as one chain on top of A, the mirror output from lo and A: 10 instead of 11 instructions per pair
+            double lo = A;
 #pragma unroll
             for (int r = 0; r < HI; ++r)
-                B += o[r] * Wo[r * RO + q];
-            out[q] += A + B;
-            out[NOUT - 1 - q] += ANTI ? B - A : A - B;
+                lo += o[r] * Wo[r * RO + q];
+            out[q] += lo;
+            out[NOUT - 1 - q] += ANTI ? lo - 2. * A : 2. * A - lo;
         }
         else
         {
@@ -218,7 +220,9 @@ struct FastCfg
 // rows directly behind the owned rows): one base pointer, ~150 instructions per element less.
 // ENERGY: the kernel also accumulates x^T A x = sum_q wgt |B x|^2 of its elements into *a.energy (for <p, A p> of the PCG:
 // saves the separate dot-product pass over two vectors).
-template < typename K, int P, int NQ, bool SPLIT, bool ENERGY >
+// AFFINE: every element of the launch is a parallelepiped (its tri-linear map is affine: l3k_mesh_create checks the vertices):
+// one Jacobian per element, inverted once per element instead of once per quadrature point.
+template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     const int64_t n_owned_nodes = a.n_owned_dofs / U;
     auto          elemOf = [&](int b) { return a.elem_begin + int64_t(b) * EW + team; };
     auto          valid  = [&](int b) { return (b < lim) & on_nn & ((int64_t(b) * EW + team) < a.elem_count); };
-    const bool have_flags = a.dirichlet != nullptr && a.elem_flags != nullptr;
+    const bool have_flags = a.elem_flags != nullptr;
     auto       loadIds    = [&](int batch, uint32_t (&ids)[N1], uint32_t& flag) {
         // "element touches a Dirichlet dof", fetched with the ids, one element ahead of its use: bit 0 for the element this
         // lane gathers (its team's), bit 1 for the element it scatters (the one of its scatter group steam)
@@ -333,7 +337,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             else if (worker && (int64_t(batch) * EW + team) < a.elem_count)
                 fg = a.elem_flags[elemOf(batch)];
         }
-        flag = (fg != 0 ? 1u : 0u) | (fs != 0 ? 2u : 0u);
+        // bit 0 / 1: the gathered / the scattered element touches a Dirichlet dof (bit 1 of the mesh's flags marks affine
+        // elements: used at launch time to select the AFFINE kernel variant for all-affine meshes)
+        flag = ((fg & 1u) ? 1u : 0u) | ((fs & 1u) ? 2u : 0u);
         if (valid(batch))
         {
             const uint32_t* en = a.elem_nodes + elemOf(batch) * NN + (lane_o - team * TEAM); // + i1 + N1 * j1
@@ -658,6 +664,15 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 }
                 hexPencilGeom(vs, eta_l, zeta_l, G);
             }
+            // affine elements: one Jacobian per element -- inverted once here instead of once per quadrature point (50 of the
+            // 139 instructions per point)
+            {
+                [[maybe_unused]] double Jm0[3][3], Ji0[3][3], x0[3], det0 = 0.;
+                if constexpr (AFFINE)
+                {
+                    hexPointOnPencil(G, 0., Jm0, x0); // (G[3] = G[5] = 0: the Jacobian does not depend on xi)
+                    det0 = inverse3(Jm0, Ji0);
+                }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
             {
@@ -683,7 +698,13 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     else // the kernel declared that it never reads the derivatives of the external fields
                         dv[0][o] = dv[1][o] = dv[2][o] = 0.;
                 }
-                qpStage< K, 1, false, 1, 0, ENERGY >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                if constexpr (AFFINE)
+                {
+                    const double xyz[3] = {G[0][0] + qp[q] * G[1][0], G[0][1] + qp[q] * G[1][1], G[0][2] + qp[q] * G[1][2]};
+                    qpStageAt< K, 1, false, 1, 0, ENERGY >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                }
+                else
+                    qpStage< K, 1, false, 1, 0, ENERGY >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -696,6 +717,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     stg(bufB, g, at(q, qa, qb), rd[1][2 * g], 2 * g + 1 < U ? rd[1][2 * g + 1] : 0.);
                     stg(bufA, g, at(q, qa, qb), rd[2][2 * g], 2 * g + 1 < U ? rd[2][2 * g + 1] : 0.);
                 }
+            }
             }
             if constexpr (ENERGY) // LDS atomic add of every pencil's share into the team's accumulator
                 atomicAdd(vs + 24, en);
@@ -1086,8 +1108,11 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
     const bool  split    = !((a.xg == nullptr || a.xg == a.x + a.n_owned_dofs) && (a.yg == nullptr || a.yg == a.y + a.n_owned_dofs));
-    auto        kernel   = a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
-                                    : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
+    // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
+    const bool  affine   = a.all_affine && !split && !a.energy && std::getenv("L3K_NO_AFFINE") == nullptr;
+    auto        kernel   = affine ? sumfactFastKernel< K, P, NQ, false, false, true >
+                           : a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
+                                      : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
     // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
     // attribute of the four variants is set once on each device, under a lock
     struct PerDevice
@@ -1110,10 +1135,11 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         PerDevice&                    pd = per_device[dev];
         if (!pd.ready)
         {
-            const void* const variants[4] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
+            const void* const variants[5] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
                                              reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
                                              reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
-                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >)};
+                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >),
+                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, true >)};
             bool ok = true;
             for (const void* f : variants)
                 ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;

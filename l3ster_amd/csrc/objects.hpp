@@ -135,6 +135,7 @@ struct l3k_mesh
     // rows in y), slots [n_shell, N) its internal nodes = exactly the nodes of [exclusive_begin, exclusive_end)
     DevBuf< uint16_t >  slot_tab;
     int                 n_shell = 0;
+    bool                all_affine = false; // every element is a parallelepiped (flags bit 1 of all elements)
     // deterministic mode: copies of the element arrays with the elements of each class (interior, border) sorted by colour;
     // det_ptr[0][c] .. det_ptr[0][c + 1] = interior elements of colour c, det_ptr[1][...] the border ones (positions in the
     // permuted arrays, which keep the interior elements first)

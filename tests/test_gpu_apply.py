@@ -72,6 +72,10 @@ MESH_CASES = [
     (system.KERNEL_DIFFUSION3D, (3, 2, 2), 1, 1, 1, 0.1),
     (system.KERNEL_DIFFUSION3D, 3, 2, 1, 2, 0.1),
     (system.KERNEL_DIFFUSION3D, 4, 3, 1, 1, 0.0),
+    # uniform meshes: every element a parallelepiped -> the affine variant of the one-wave kernel (one Jacobian per element)
+    (system.KERNEL_DIFFUSION3D, (3, 2, 2), 6, 1, 1, 0.0),
+    (system.KERNEL_DIFFUSION3D, (5, 4, 3), 4, 1, 1, 0.0),
+    (system.KERNEL_ADVDIFF3D, 3, 4, 1, 1, 0.0),
     (system.KERNEL_DIFFUSION3D, (5, 4, 3), 4, 1, 1, 0.1),
     (system.KERNEL_DIFFUSION3D, 2, 5, 1, 1, 0.1),
     (system.KERNEL_DIFFUSION3D, 3, 6, 1, 1, 0.1),

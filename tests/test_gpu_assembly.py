@@ -110,15 +110,19 @@ def test_mass_kernel_pins_weight_times_jacobian(ctx, p, vo):
     assert np.abs(K - K_ref).max() < 1e-12 * np.abs(K_ref).max()
     ones = np.zeros(K.shape[0])
     ones[0::2] = 1.0
+    import os
+    before = os.environ.get("L3K_GENERIC_BELOW")
     for generic_below in ("0", "1000000"):  # the one-wave kernel and the generic LDS kernel
-        import os
         os.environ["L3K_GENERIC_BELOW"] = generic_below
         try:
             X, Y = dev(ones[None, :]), dev(np.zeros((1, K.shape[0])))
             mf.apply(X, Y, 1.0, 0.0)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("L3K_GENERIC_BELOW", None)
+            if before is None:
+                os.environ.pop("L3K_GENERIC_BELOW", None)
+            else:
+                os.environ["L3K_GENERIC_BELOW"] = before
         y = Y.cpu().numpy()[0]
         np.testing.assert_allclose(y, K_ref @ ones, atol=1e-12)
         assert abs(y[0::2].sum() - vol) < 1e-11 and np.abs(y[1::2]).max() < 1e-13
