@@ -87,7 +87,19 @@ def cpu_baseline(part, mask, x_owned, p, U, applies=3):
     except Exception:  # pragma: no cover - fall back to the prebuilt x86-64-v3 library
         L = O.lib()
         flavour = "-O3 -march=x86-64-v3"
-    cores = len(os.sched_getaffinity(0))  # every core the affinity mask gives (printed)
+    # every core this job may use: the affinity mask, capped by the container's CPU quota where one is set (a GPU box
+    # shows all of the host's CPUs in the mask but gives one GPU's job a share of them; threads beyond the share only
+    # contend for the scatter's atomics)
+    mask_cores = len(os.sched_getaffinity(0))
+    cores = mask_cores
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(mask_cores, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    if os.environ.get("L3K_CPU_BASELINE_THREADS"):
+        cores = int(os.environ["L3K_CPU_BASELINE_THREADS"])
     om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
     x = np.asfortranarray(x_owned.reshape(-1, 1))
     y = np.zeros_like(x, order="F")
@@ -101,7 +113,7 @@ def cpu_baseline(part, mask, x_owned, p, U, applies=3):
     return {"value": dofs / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
             "sample": f"median of {applies} applies on the benchmark mesh itself ({part.n_elems} order-{p} elements, {dofs} dofs, "
                       f"the benchmark's x), oracle/oracle.cpp orc_mf_apply {flavour}, {cores} threads "
-                      f"(all cores of the affinity mask), {' / '.join(f'{t:.2f}' for t in times)} s"}, y
+                      f"(affinity mask: {mask_cores} CPUs, CPU quota applied where the container sets one), {' / '.join(f'{t:.2f}' for t in times)} s"}, y
 
 
 def main():
@@ -237,10 +249,9 @@ def main():
                               "kernel_ms": ms, "kernel_ms_mean": float(np.mean(kernel_times)), "kernel_ms_stat": "median of the timed launches",
                               "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
                               "algorithmic_bytes_per_launch": alg_bytes,
-                              "fp64_note": "the kernel is FP64-VALU bound, not HBM bound (DESIGN.md 4.1): executed vector "
-                                           "FP64 flops per element from the ISA, peak = 78.6 TFLOP/s spec (57.5 measured, "
-                                           "tools/fp64_peak.hip); the FP64 ceiling of this instruction stream is ~30 % of "
-                                           "the HBM roofline",
+                              "fp64_note": "not HBM-bound (DESIGN.md 4.1): executed vector FP64 flops per element from the ISA against the "
+                                           "78.6 TFLOP/s FP64 peak (vector and matrix FP64 share one pipe on this part); the VALU, LDS "
+                                           "and atomic ceilings of this formulation sit at 0.36-0.38 of the HBM roofline",
                               "fp64_tflops": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12,
                               "fp64_peak_tflops": 78.6}
         if world == 1 and op is None and p == 6:

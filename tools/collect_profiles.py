@@ -8,7 +8,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, ROOT)
+import bench as bench_module  # noqa: E402  (kernel_source_hash: the traffic is keyed to the kernel sources it was measured on)
+
+
+def is_p6(name):
+    """the headline kernel: sumfactFastKernel<Diffusion3D, 6, 7, ...> (the bench line also runs the order-4 instance)"""
+    return "sumfactFastKernel" in name and "Diffusion3D, 6, 7" in name
 
 
 def last_json_line(path):
@@ -23,7 +30,7 @@ with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w") as out:
     out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
               "  (MI355X, 64^3 order-6 Diffusion3D apply)\n")
     trace = [r for r in csv.DictReader(open(os.path.join(SRC, "stats", "stats_kernel_trace.csv")))
-             if "sumfactFastKernel" in r["Kernel_Name"]]
+             if is_p6(r["Kernel_Name"])]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace]
     out.write(f"# sumfactFastKernel launches in order (ms): {' '.join(f'{d:.3f}' for d in dur)}; the 10 timed ones (after 3 warm-up "
               f"launches) average {sum(dur[3:]) / max(1, len(dur[3:])):.3f} ms (the Average column includes the cold first launches)\n")
@@ -34,7 +41,7 @@ with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w") as out:
 def counter_mean(name, counter):
     vals = []
     for row in csv.DictReader(open(os.path.join(SRC, name, f"{name}_counter_collection.csv"))):
-        if "sumfactFastKernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+        if is_p6(row["Kernel_Name"]) and row["Counter_Name"] == counter:
             vals.append(float(row["Counter_Value"]))
     return sum(vals) / len(vals), len(vals)
 
@@ -44,9 +51,36 @@ write, nw = counter_mean("write", "WRITE_SIZE")
 traffic = (2.0 * fetch + write) * 1024.0  # MI355X_MICROARCH.md: counters in KiB; gfx950 fetch counts 64 B per 128-B read
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (resp. WRITE_SIZE) --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
            "kernel": "sumfactFastKernel<Diffusion3D,6,7>", "workload": "64x64x64 order 6", "launches_averaged": [nf, nw],
+           "kernel_source_sha256": bench_module.kernel_source_hash(),
            "FETCH_SIZE_per_launch": fetch, "WRITE_SIZE_per_launch": write, "unit": "KiB (counter units)",
            "correction": "fetch x2 (gfx950 wide-read under-count), write x1", "traffic_bytes_per_launch": traffic,
            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]},
           open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+import glob
+acc = {}
+for f in glob.glob(os.path.join(SRC, "sq*", "sq*_counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        if is_p6(row["Kernel_Name"]):
+            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+if acc:
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    with open(os.path.join(DST, f"{tag}_pmc_fast_kernel_64cubed.txt"), "w") as out:
+        out.write("# rocprofv3 --pmc <SQ set> --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (two passes), sumfactFastKernel<Diffusion3D,6,7>,\n"
+                  "# 64^3 elements, mean per launch, chip-wide sums\n")
+        cyc = m.get("SQ_BUSY_CU_CYCLES", 0.0) / 256
+        if cyc:
+            out.write(f"#   cycles per launch (SQ_BUSY_CU_CYCLES / 256 CUs)              = {cyc:.4g}\n")
+            if "SQ_ACTIVE_INST_VALU" in m:
+                out.write(f"#   VALU busy = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles)        = {100 * 4 * m['SQ_ACTIVE_INST_VALU'] / (1024 * cyc):.1f} %\n")
+            if "SQ_WAVE_CYCLES" in m:
+                out.write(f"#   resident waves per CU = 4*SQ_WAVE_CYCLES / (256 * cycles)        = {4 * m['SQ_WAVE_CYCLES'] / (256 * cyc):.2f}\n")
+        if "SQ_LDS_IDX_ACTIVE" in m and cyc:
+            out.write(f"#   LDS pipe active = SQ_LDS_IDX_ACTIVE / (256 * cycles)             = {100 * m['SQ_LDS_IDX_ACTIVE'] / (256 * cyc):.1f} %, "
+                      f"of which bank conflicts {100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / m['SQ_LDS_IDX_ACTIVE']:.1f} %\n")
+        if "SQ_INSTS_VALU" in m:
+            out.write(f"#   instructions per element: VALU {m['SQ_INSTS_VALU'] / 262144:.0f}, LDS {m.get('SQ_INSTS_LDS', 0) / 262144:.0f}, SALU "
+                      f"{m.get('SQ_INSTS_SALU', 0) / 262144:.0f}, SMEM {m.get('SQ_INSTS_SMEM', 0) / 262144:.0f}\n")
+        for k in sorted(m):
+            out.write(f"{k:28s} n={len(acc[k])} mean={m[k]:.4g}\n")
 print(json.dumps({"value": bench["value"], "kernel_ms": bench["roofline"]["kernel_ms"], "frac": bench["roofline"]["frac"],
                   "traffic_GB": traffic / 1e9}))

@@ -9,5 +9,12 @@ timeout -k 10 300 python bench.py --order 4 --no-cpu-baseline > "$OUT/bench_orde
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || exit 1
+# SQ counters of the element kernel in the same bench command (three passes)
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/sq$i" -o sq$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/sq$i.log" 2>&1 || exit 1
+done
 find "$OUT" -name "*.csv" | head -20
 cat "$OUT/bench.json"
