@@ -156,7 +156,7 @@ def test_config5_partitioned_pcg_advdiff_order4():
     E = 7, velocity = 3 interpolated fields), order 4, element partition over 8 ranks (2 x 2 x 2; threads
     sharing the GPU, queues in place of RCCL), Jacobi-PCG driven by the partitioned matrix-free apply with all-reduced
     scalars, rel. tol 1e-6 -- against the same PCG on the CPU with the oracle's operator on the whole mesh:
-    iterations to tolerance +-1, solution to 1e-7 (relative L2)."""
+    iterations to tolerance +-1; both solves are then continued to 1e-11 and the solutions agree to 1e-7 (relative L2)."""
     import queue
     import threading
     from l3ster_amd.distributed import DistributedOperator, HaloPlan
@@ -193,8 +193,11 @@ def test_config5_partitioned_pcg_advdiff_order4():
             g = torch.as_tensor(dirichlet_values(part, mask)[:n_owned], device="cuda")
             diag, rhs = op.diag_rhs(g[None, :])
             x = torch.zeros(n_owned, dtype=torch.float64, device="cuda")
-            res = solve.pcg_distributed(op, c, rhs[0], x, solve.jacobi_inverse_native(c, diag), tol=tol, residual_scaling="rhs",
-                                        max_iters=20000, allreduce=red.bind(rank))
+            minv = solve.jacobi_inverse_native(c, diag)
+            res = solve.pcg_distributed(op, c, rhs[0], x, minv, tol=tol, residual_scaling="rhs", max_iters=20000, allreduce=red.bind(rank))
+            # the iterates of two runs that both meet 1e-6 differ by about that much: the solutions are compared after
+            # continuing to 1e-11
+            solve.pcg_distributed(op, c, rhs[0], x, minv, tol=1e-11, residual_scaling="rhs", max_iters=20000, allreduce=red.bind(rank))
             torch.cuda.synchronize()
             out[rank] = (res.num_iters, x.cpu().numpy(), part.node_grid_id[:part.n_owned_nodes].copy())
         except Exception as exc:  # pragma: no cover
@@ -221,8 +224,9 @@ def test_config5_partitioned_pcg_advdiff_order4():
         o.copy_(torch.as_tensor(O.mf_apply(om, kid, v.numpy().reshape(-1, 1), kparams=kpar, nthreads=4)[:, 0]))
 
     x_ref = torch.zeros(len(d_ref), dtype=torch.float64)
-    res_ref = solve.cg(apply_cpu, torch.as_tensor(r_ref[:, 0].copy()), x_ref, solve.jacobi_inverse(torch.as_tensor(d_ref)), tol=tol,
-                       residual_scaling="rhs", max_iters=20000)
+    minv_ref = solve.jacobi_inverse(torch.as_tensor(d_ref))
+    res_ref = solve.cg(apply_cpu, torch.as_tensor(r_ref[:, 0].copy()), x_ref, minv_ref, tol=tol, residual_scaling="rhs", max_iters=20000)
+    solve.cg(apply_cpu, torch.as_tensor(r_ref[:, 0].copy()), x_ref, minv_ref, tol=1e-11, residual_scaling="rhs", max_iters=20000)
     iters = {v[0] for v in out.values()}
     assert len(iters) == 1, iters
     assert abs(iters.pop() - res_ref.num_iters) <= 1, (out[0][0], res_ref.num_iters)
