@@ -32,9 +32,9 @@ PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # executed FP64 flops per element of sumfactFastKernel<Diffusion3D> (ISA count: (fma + fmac) * 2 + mul + add, times the
 # active lanes per element): order 6: 4 460 lane-flops x 49 lanes
 FP64_FLOP_PER_ELEM = {6: 4460 * 49}
-# executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u): per workgroup 25
-# iterations of (stage 1: 2*49*112, stage 2: 2744 outputs * 15.75, stage 3: 490 threads * 10 outputs * 28) FMAs + G
-SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (25 * (2 * 49 * 112 + 2744 * 15.75 + 490 * 10 * 28) + 343 * 16 * 7)
+# executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u): per workgroup 7
+# iterations (one bx' each) of stage 1: 7 pairs x 49 x 112, stage 2: 343 rows x 441, stage 3: 343 rows x 49 columns x 28 FMAs, + G
+SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (7 * (7 * 49 * 112 + 343 * 441 + 343 * 49 * 28) + 343 * 16 * 7)
 
 
 def algorithmic_bytes_per_dof(p, U, F=0):
@@ -288,7 +288,7 @@ def main():
                                         "algorithm": "sum-factorised assembly on index pairs (O(n^7) per pair of unknowns), FP64 vector pipe",
                                         "roofline": {"bound": "mfma", "achieved": rate * sf_flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                                      "frac": rate * sf_flops / 1e12 / 78.6,
-                                                     "flops": "executed: 96.5 MFLOP per element; FP64 matrix and vector pipes are one pipe "
+                                                     "flops": "executed: 93.2 MFLOP per element; FP64 matrix and vector pipes are one pipe "
                                                               "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)",
                                                      "dense_equivalent_tflops": rate * dense_flops / 1e12},
                                         "dense_mfma_kernel": {"value": rate_dense, "unit": "element matrices/s",

@@ -17,6 +17,9 @@
 
 #include "sumfact_apply.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace l3k::dev
 {
 using mfma_d4 = __attribute__((ext_vector_type(4))) double;
@@ -309,46 +312,44 @@ template < int P, int NQ >
 struct SfAsmCfg
 {
     static constexpr int N1 = P + 1, N2 = N1 * N1, NQP = NQ * NQ * NQ;
-    static constexpr int PAIRS = 2;                       // (bx, bx') pairs per iteration
-    static constexpr int TR = 2, TC = 5;                  // outputs per thread in stage 3: TR rows (strided by RT) x TC columns
-    static constexpr int ROWS = PAIRS * N2;               // stage-3 rows per iteration: (pair, by, by')
-    static constexpr int RT = (ROWS + TR - 1) / TR, CT = (N2 + TC - 1) / TC;
-    static constexpr int K3 = 4 * NQ;                     // stage-3 contraction length: (tz, qz)
-    static constexpr int BROW = ROWS + 1;                 // B stored [K3][BROW] (row index fastest; +1 against bank conflicts)
-    static constexpr int PZROW = CT * TC;                 // Pz stored [K3][PZROW]
-    // G | P | A | B | Pz
-    static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * NQ +
-                                                    size_t(K3) * BROW + size_t(K3) * PZROW);
-    static constexpr bool feasible = lds <= 160 * 1024 && RT * CT <= 1024;
-    // two waves per SIMD hide the LDS round trips of the three stages (one workgroup per CU: G alone is 16 nq^3 doubles)
-    static constexpr int  threads  = RT * CT <= 512 ? 512 : 1024;
+    static constexpr int PAIRS = N1;                      // one iteration = all bx for one bx'
+    static constexpr int ROWS  = PAIRS * N2;              // one thread per row (bx, by, by')
+    static constexpr int K3    = 4 * NQ;                  // stage-3 contraction length: (tz, qz)
+    static constexpr int AROW  = NQ;                      // (no padding: at order 6 the workgroup then needs 79.6 KB -> two per CU)
+    static constexpr int threads = ((ROWS + 63) / 64) * 64;
+    // G | P | A
+    static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * AROW);
+    static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
+    static constexpr size_t pz_doubles = size_t(N2) * K3; // the z product table in global memory: [column (bz, bz')][(tz, qz)]
 };
 
+// Stage 1 is cooperative (A[bx][group][qz][qy] for the iteration's bx', through LDS); stages 2 and 3 are fused per row:
+// the thread of row (bx, by, by') forms its 4 nq values B[tz][qz] in registers from its own rows of the y product tables (28
+// doubles loaded once per workgroup) and the A arrays (LDS reads shared by the 49 threads of a bx), then runs over the n^2
+// columns (bz, bz') with the z product table read by SCALAR loads (wave-uniform: 28 SGPR-pair operands per column, no LDS
+// operand traffic in the stage that holds 72 % of the flops).
 template < typename K, int P, int NQ >
 __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
-                                                                                       int64_t elem0)
+                                                                                       const double* __restrict__ pz_table, int64_t elem0)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = SfAsmCfg< P, NQ >;
-    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, TR = C::TR, TC = C::TC, RT = C::RT, CT = C::CT;
-    constexpr int         K3 = C::K3, BROW = C::BROW, PZROW = C::PZROW, ROWS = C::ROWS, NT = C::threads, ND = N1 * N2 * U;
+    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, ROWS = C::ROWS, K3 = C::K3, AROW = C::AROW;
+    constexpr int         NT = C::threads, ND = N1 * N2 * U;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
     // the 16 terms (k, k') by group: type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1); groups (ty, tz):
     // 0 (II,II)  1 (DI,II)  2 (ID,II)  3 (DD,II)  4 (II,DI)  5 (II,ID)  6 (II,DD)  7 (DI,ID)  8 (ID,DI)
 
     extern __shared__ double lds[];
-    double* const            G  = lds;                       // [16][NQP]
-    double* const            Pt = G + 16 * NQP;              // [4][N2][NQ]
-    double* const            A  = Pt + 4 * N2 * NQ;          // [PAIRS][9][NQ*NQ]
-    double* const            B  = A + PAIRS * 9 * NQ * NQ;   // [K3 = (tz, qz)][BROW]: row = pair * N2 + (by + N1 by')
-    double* const            Pz = B + K3 * BROW;             // [K3][PZROW]: column = bz + N1 bz' (zero padded)
+    double* const            G  = lds;              // [16][NQP]
+    double* const            Pt = G + 16 * NQP;     // [4][N2][NQ]
+    double* const            A  = Pt + 4 * N2 * NQ; // [PAIRS][9][NQ (qz)][AROW (qy, padded)]
 
     const int     tid = threadIdx.x;
     const int64_t el  = blockIdx.y;
-    // unknown pair of this workgroup: u' <= u
-    int u = 0, rem = blockIdx.x;
+    int           u = 0, rem = blockIdx.x; // unknown pair of this workgroup: u' <= u
     while (rem > u)
     {
         rem -= u + 1;
@@ -364,18 +365,6 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
         const double* T0 = a.tables + ((t & 1) ? TL.offD() : TL.offI());
         const double* T1 = a.tables + ((t & 2) ? TL.offD() : TL.offI());
         Pt[i]            = T0[b1 * NQ + q] * T1[b1p * NQ + q];
-    }
-    for (int i = tid; i < K3 * PZROW; i += NT)
-    {
-        const int k3 = i / PZROW, c = i - k3 * PZROW, tz = k3 / NQ, qz = k3 - tz * NQ;
-        double    v  = 0.;
-        if (c < N2)
-        {
-            const double* T0 = a.tables + ((tz & 1) ? TL.offD() : TL.offI());
-            const double* T1 = a.tables + ((tz & 2) ? TL.offD() : TL.offI());
-            v                = T0[(c % N1) * NQ + qz] * T1[(c / N1) * NQ + qz];
-        }
-        Pz[i] = v;
     }
     const double* cel = cbuf + el * NQP * CS;
     for (int q = tid; q < NQP; q += NT)
@@ -405,127 +394,109 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     }
     __syncthreads();
 
-    // stage-3 tile of this thread
-    const int  rt = tid % RT, ct = tid / RT;
-    const bool tile = ct < CT;
-    double     csum = 0.;
-    double*    Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
+    // this thread's row (bx = pp, by, by') and its rows of the y product tables
+    const bool has_row = tid < ROWS;
+    const int  row = has_row ? tid : 0, pp = row / N2, bb = row - pp * N2, by = bb % N1, byp = bb / N1;
+    double     py[4][NQ];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+        for (int qy = 0; qy < NQ; ++qy)
+            py[ty][qy] = Pt[(ty * N2 + bb) * NQ + qy];
 
-    constexpr int NPAIR = N1 * N1;
-    for (int pair0 = 0; pair0 < NPAIR; pair0 += PAIRS)
+    double  csum = 0.;
+    double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
+    const __attribute__((address_space(4))) double* const pz =
+        reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(pz_table));
+
+    for (int bxp = 0; bxp < N1; ++bxp)
     {
-        // ---- stage 1: A[pp][g][qy][qz]; the group is the slowest index of the work list, so a wave runs one group's
+        const int pair0 = bxp * N1; // pairs (bx, bx') = bx + N1 bx', bx = 0 .. N1-1
+        // ---- stage 1: A[bx][g][qz][qy]; the group is the slowest index of the work list, so a wave runs one group's
         // compile-time term list
         for (int i = tid; i < 9 * PAIRS * NQ * NQ; i += NT)
         {
-            const int g = i / (PAIRS * NQ * NQ), r = i - g * (PAIRS * NQ * NQ), pp = r / (NQ * NQ), qyz = r - pp * (NQ * NQ);
-            const int pair = pair0 + pp;
+            const int g = i / (PAIRS * NQ * NQ), r = i - g * (PAIRS * NQ * NQ), bx = r / (NQ * NQ), qyz = r - bx * (NQ * NQ);
+            const int pair = pair0 + bx;
             double    acc  = 0.;
-            if (pair < NPAIR)
-            {
-                const auto term = [&](int k, int kp) {
-                    const int     tx = (k == 1) + 2 * (kp == 1);
-                    const double* px = Pt + (tx * N2 + pair) * NQ;
-                    const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
+            const auto term = [&](int k, int kp) {
+                const int     tx = (k == 1) + 2 * (kp == 1);
+                const double* px = Pt + (tx * N2 + pair) * NQ;
+                const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
 #pragma unroll
-                    for (int qx = 0; qx < NQ; ++qx)
-                        acc += px[qx] * gq[qx];
-                };
-                switch (g)
-                {
-                case 0: term(0, 0), term(0, 1), term(1, 0), term(1, 1); break; // (ty, tz) = (II, II)
-                case 1: term(2, 0), term(2, 1); break;                         // (DI, II)
-                case 2: term(0, 2), term(1, 2); break;                         // (ID, II)
-                case 3: term(2, 2); break;                                     // (DD, II)
-                case 4: term(3, 0), term(3, 1); break;                         // (II, DI)
-                case 5: term(0, 3), term(1, 3); break;                         // (II, ID)
-                case 6: term(3, 3); break;                                     // (II, DD)
-                case 7: term(2, 3); break;                                     // (DI, ID)
-                default: term(3, 2); break;                                    // (ID, DI)
-                }
+                for (int qx = 0; qx < NQ; ++qx)
+                    acc += px[qx] * gq[qx];
+            };
+            switch (g)
+            {
+            case 0: term(0, 0), term(0, 1), term(1, 0), term(1, 1); break; // (ty, tz) = (II, II)
+            case 1: term(2, 0), term(2, 1); break;                         // (DI, II)
+            case 2: term(0, 2), term(1, 2); break;                         // (ID, II)
+            case 3: term(2, 2); break;                                     // (DD, II)
+            case 4: term(3, 0), term(3, 1); break;                         // (II, DI)
+            case 5: term(0, 3), term(1, 3); break;                         // (II, ID)
+            case 6: term(3, 3); break;                                     // (II, DD)
+            case 7: term(2, 3); break;                                     // (DI, ID)
+            default: term(3, 2); break;                                    // (ID, DI)
             }
-            A[(pp * 9 + g) * NQ * NQ + qyz] = acc;
+            A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = acc;
         }
         __syncthreads();
-        // ---- stage 2: B[(tz, qz)][pp * N2 + (by, by')]
-        for (int i = tid; i < K3 * ROWS; i += NT)
+        if (has_row)
         {
-            const int k3 = i / ROWS, row = i - k3 * ROWS, tz = k3 / NQ, qz = k3 - tz * NQ, pp = row / N2, bb = row - pp * N2;
-            double    acc = 0.;
+            // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]
+            double B[4][NQ];
 #pragma unroll
-            for (int ty = 0; ty < 4; ++ty)
-            {
-                const int g = tz == 0 ? ty : (tz == 1 ? (ty == 0 ? 4 : (ty == 2 ? 8 : -1)) : (tz == 2 ? (ty == 0 ? 5 : (ty == 1 ? 7 : -1)) : (ty == 0 ? 6 : -1)));
-                if (g >= 0)
+            for (int tz = 0; tz < 4; ++tz)
+#pragma unroll
+                for (int qz = 0; qz < NQ; ++qz)
                 {
-                    const double* py = Pt + (ty * N2 + bb) * NQ;
-                    const double* aq = A + (pp * 9 + g) * NQ * NQ + qz * NQ; // [qz][qy]: A index = qy + NQ * qz
+                    double acc = 0.;
 #pragma unroll
-                    for (int qy = 0; qy < NQ; ++qy)
-                        acc += py[qy] * aq[qy];
-                }
-            }
-            B[k3 * BROW + row] = acc;
-        }
-        __syncthreads();
-        // ---- stage 3: M[row][col] = sum_k3 B[k3][row] Pz[k3][col], TR x TC outputs per thread
-        if (tile)
-        {
-            double m[TR][TC];
-#pragma unroll
-            for (int i = 0; i < TR; ++i)
-#pragma unroll
-                for (int j = 0; j < TC; ++j)
-                    m[i][j] = 0.;
-#pragma unroll 4
-            for (int k3 = 0; k3 < K3; ++k3)
-            {
-                double br[TR], pc[TC];
-#pragma unroll
-                for (int i = 0; i < TR; ++i) // (rows rt + RT * i: consecutive lanes read consecutive doubles)
-                    br[i] = rt + RT * i < ROWS ? B[k3 * BROW + rt + RT * i] : 0.;
-#pragma unroll
-                for (int j = 0; j < TC; ++j)
-                    pc[j] = Pz[k3 * PZROW + ct * TC + j];
-#pragma unroll
-                for (int i = 0; i < TR; ++i)
-#pragma unroll
-                    for (int j = 0; j < TC; ++j)
-                        m[i][j] += br[i] * pc[j];
-            }
-            // ---- output: K[(b,u),(b',u')], b = bx + N1 (by + N1 bz), b' likewise; blocks u' < u whole, u' = u lower part; mirrored
-#pragma unroll
-            for (int i = 0; i < TR; ++i)
-            {
-                const int row = rt + RT * i, pp = row / N2, bb = row - pp * N2, pair = pair0 + pp;
-                if (row >= ROWS || pair >= NPAIR)
-                    continue;
-                const int bx = pair % N1, bxp = pair / N1, by = bb % N1, byp = bb / N1;
-#pragma unroll
-                for (int j = 0; j < TC; ++j)
-                {
-                    const int col = ct * TC + j;
-                    if (col >= N2)
-                        continue;
-                    const int bz = col % N1, bzp = col / N1;
-                    const int b = bx + N1 * (by + N1 * bz), bp = bxp + N1 * (byp + N1 * bzp);
-                    if (u == up && bp > b)
-                        continue;
-                    const int    gi = b * U + u, gj = bp * U + up;
-                    const double v  = m[i][j];
-                    if (Kel)
+                    for (int ty = 0; ty < 4; ++ty)
                     {
-                        Kel[int64_t(gi) * ND + gj] = v;
-                        if (gi != gj)
-                            Kel[int64_t(gj) * ND + gi] = v;
+                        constexpr int gtab[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}}; // [ty][tz]
+                        const int     g = gtab[ty][tz];
+                        if (g >= 0)
+                        {
+                            const double* aq = A + ((pp * 9 + g) * NQ + qz) * AROW;
+#pragma unroll
+                            for (int qy = 0; qy < NQ; ++qy)
+                                acc += py[ty][qy] * aq[qy];
+                        }
                     }
-                    csum += v * (1 + ((gi * 31 + gj * 17) % 7));
-                    if (gi != gj)
-                        csum += v * (1 + ((gj * 31 + gi * 17) % 7));
+                    B[tz][qz] = acc;
                 }
+            // ---- stage 3: M[row][(bz,bz')] = sum_{tz,qz} B[tz][qz] Pz[(bz,bz')][(tz,qz)], the table through scalar loads
+            const int rowb = pp + N1 * by, rowbp = bxp + N1 * byp;
+            // (a software pipeline over half columns -- the next scalar loads issued behind the wait for the current ones -- was
+            // tried: 147 k instead of 165 k matrices/s; the three resident waves per SIMD hide the scalar-load latency better)
+            for (int c = 0; c < N2; ++c)
+            {
+                const __attribute__((address_space(4))) double* pc = pz + c * K3;
+                double                                          m  = 0.;
+#pragma unroll
+                for (int tz = 0; tz < 4; ++tz)
+#pragma unroll
+                    for (int qz = 0; qz < NQ; ++qz)
+                        m += B[tz][qz] * pc[tz * NQ + qz];
+                const int bz = c % N1, bzp = c / N1;
+                const int b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
+                if (u == up && bp > b) // diagonal blocks: the lower part only (mirrored)
+                    continue;
+                const int gi = b * U + u, gj = bp * U + up;
+                if (Kel)
+                {
+                    Kel[int64_t(gi) * ND + gj] = m;
+                    if (gi != gj)
+                        Kel[int64_t(gj) * ND + gi] = m;
+                }
+                // checksum weight 1 + (31 gi + 17 gj) mod 7, the same for the mirrored entry (31 = 17 = 3 mod 7)
+                const double wgt = double(1 + (gi * 31 + gj * 17) % 7);
+                csum += (gi != gj ? 2. : 1.) * wgt * m;
             }
         }
-        __syncthreads(); // A and B are rewritten by the next iteration
+        __syncthreads(); // A is rewritten by the next iteration
     }
     if (a.checksum)
     {
@@ -533,9 +504,10 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
         double* red = A; // (free after the last barrier)
         red[tid]    = csum;
         __syncthreads();
-        for (int w = NT / 2; w > 0; w >>= 1)
+        constexpr int P2 = NT <= 64 ? 64 : (NT <= 128 ? 128 : (NT <= 256 ? 256 : (NT <= 512 ? 512 : 1024))); // (NT = 384 at order 6)
+        for (int w = P2 / 2; w > 0; w >>= 1)
         {
-            if (tid < w)
+            if (tid < w && tid + w < NT)
                 red[tid] += red[tid + w];
             __syncthreads();
         }
@@ -579,18 +551,44 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         if (!dense)
         {
             auto ks = assembleSumfactKernel< K, P, NQ >;
-            static bool sf_attr = false;
-            if (!sf_attr)
+            // the z product table Pz[(bz,bz')][(tz,qz)] = T_s[bz][qz] T_s'[bz'][qz] depends on (P, NQ) only: built once per device
+            static double*    pz_dev[64] = {};
+            static std::mutex pz_mutex;
+            int               dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64)
             {
-                if (hipFuncSetAttribute(reinterpret_cast< const void* >(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) != hipSuccess)
+                setError("device index %d not supported", dev);
+                return -3;
+            }
+            {
+                std::lock_guard< std::mutex > lock{pz_mutex};
+                if (!pz_dev[dev])
                 {
-                    setError("hipFuncSetAttribute failed for the sum-factorised assembly kernel");
-                    return -3;
+                    if (hipFuncSetAttribute(reinterpret_cast< const void* >(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) != hipSuccess)
+                    {
+                        setError("hipFuncSetAttribute failed for the sum-factorised assembly kernel");
+                        return -3;
+                    }
+                    constexpr TableLayout TL{P + 1, NQ};
+                    std::vector< double > pz(S::pz_doubles);
+                    const double *        tI = a.tables_host + TL.offI(), *tD = a.tables_host + TL.offD();
+                    for (int c = 0; c < S::N2; ++c)
+                        for (int tz = 0; tz < 4; ++tz)
+                            for (int qz = 0; qz < NQ; ++qz)
+                                pz[size_t(c) * S::K3 + tz * NQ + qz] = ((tz & 1) ? tD : tI)[(c % S::N1) * NQ + qz] * ((tz & 2) ? tD : tI)[(c / S::N1) * NQ + qz];
+                    double* d = nullptr;
+                    if (hipMalloc(reinterpret_cast< void** >(&d), pz.size() * sizeof(double)) != hipSuccess ||
+                        hipMemcpy(d, pz.data(), pz.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+                    {
+                        setError("allocation of the assembly product table failed");
+                        return -3;
+                    }
+                    pz_dev[dev] = d;
                 }
-                sf_attr = true;
             }
             hipLaunchKernelGGL(ks, dim3(U * (U + 1) / 2, static_cast< unsigned >(a.elem_count)), dim3(S::threads), S::lds, stream, a, cbuf,
-                               int64_t(a.elem_begin_out));
+                               pz_dev[dev], int64_t(a.elem_begin_out));
         }
     if (dense)
         hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,
