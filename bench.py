@@ -120,7 +120,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=15, help="untimed applies (the clock of an idle GPU ramps over the first ~10 launches)")
     ap.add_argument("--ne", type=int, default=64, help="elements per edge of each GPU's block")
     ap.add_argument("--order", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -27,13 +27,16 @@ bench = last_json_line(os.path.join(SRC, "bench.json"))
 json.dump(bench, open(os.path.join(DST, f"{tag}_bench.json"), "w"), indent=1)
 json.dump(last_json_line(os.path.join(SRC, "bench_order4.json")), open(os.path.join(DST, f"{tag}_bench_order4.json"), "w"), indent=1)
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w") as out:
-    out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
-              "  (MI355X, 64^3 order-6 Diffusion3D apply)\n")
+    out.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline  (the default run: 15 warm-up + 20 timed"
+              " applies; MI355X, 64^3 order-6 Diffusion3D apply)\n")
     trace = [r for r in csv.DictReader(open(os.path.join(SRC, "stats", "stats_kernel_trace.csv")))
              if is_p6(r["Kernel_Name"])]
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace]
-    out.write(f"# sumfactFastKernel launches in order (ms): {' '.join(f'{d:.3f}' for d in dur)}; the 10 timed ones (after 3 warm-up "
-              f"launches) average {sum(dur[3:]) / max(1, len(dur[3:])):.3f} ms (the Average column includes the cold first launches)\n")
+    W = 15
+    timed = sorted(dur[W:W + 20])
+    out.write(f"# order-6 sumfactFastKernel launches in order (ms): {' '.join(f'{d:.3f}' for d in dur)}; the 20 timed ones (after {W} warm-up "
+              f"launches): average {sum(timed) / max(1, len(timed)):.3f} ms, median {timed[len(timed) // 2] if timed else 0:.3f} ms (the Average column "
+              f"below includes the warm-up launches, during which the clock of the idle GPU ramps)\n")
     for row in csv.reader(open(os.path.join(SRC, "stats", "stats_kernel_stats.csv"))):
         out.write(",".join('"' + c[:90] + '"' if i == 0 and row[0] != "Name" else c for i, c in enumerate(row)) + "\n")
 

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/refresh
 rm -rf "$OUT" && mkdir -p "$OUT"
 timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 timeout -k 10 300 python bench.py --order 4 --no-cpu-baseline > "$OUT/bench_order4.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python bench.py --no-cpu-baseline > "$OUT/stats.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/write.log" 2>&1 || exit 1
 # SQ counters of the element kernel in the same bench command (three passes)
