@@ -372,6 +372,7 @@ typedef struct
                                               neighbour (import receive / export send); ghosts are sorted by global id */
     const uint8_t*  elem_boundary;         /* [n_elems] bit s set if side s of the element lies on cube side s: the
                                               boundary views of makeCubeMesh (mesh/primitives/CubeMesh.hpp:66-138)   */
+    const int64_t*  ghost_global_id;       /* [n_ghost] global node id of every ghost (ascending)                    */
 } l3k_hostmesh_view;
 int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* out);
 
@@ -394,6 +395,49 @@ int l3k_results_save(const char* path, const char* comment, size_t n_fields, int
                      int64_t n_local_nodes, const double* fields, size_t ld, int write_header);
 int l3k_results_info(const char* path, size_t* n_fields, size_t* n_nodes);
 int l3k_results_load(const char* path, size_t field, int64_t n, const int64_t* node_ids, int64_t node_begin, double* out);
+
+/* ---- native mesh file (host only; post/NativeIO.hpp:75-108 save(comm, mesh, path, comment), :161-232
+ * extractSavedPartitionInfo / loadUnifiedMesh / loadPartitionedMesh; mesh/MeshUtils.hpp:318-360 serializeMesh /
+ * deserializeMesh; util/Serialization.hpp:20-66) ------------------------------------------------------------------------
+ * "L3STER mesh file\nv1.0\n// <comment>\n", size_t n_parts, n_parts size_t part sizes, then every rank's serialised
+ * MeshPartition<order>: its domains in ascending id, each the elements of type Hex, Quad, Line (mesh/ElementType.hpp:11-16)
+ * as { uint64 nodes[(p+1)^d] (GLOBAL ids); double vertices[2^d][3]; uint64 id }, then nodes_begin, num_owned_nodes and
+ * the boundary domain ids.  The structs below are the structure-of-arrays view of one part.  Writing: every rank
+ * computes its size (l3k_meshfile_part_bytes), the sizes are gathered by the caller (the reference: comm.gather, :83),
+ * every rank then calls l3k_meshfile_save with the full size table and the SAME comment (its length fixes the offsets of
+ * the parts); exactly one passes write_header != 0; no ordering between the ranks' calls is required.  Reading: l3k_meshfile_load parses part `part` as a mesh of the given order
+ * (the order is not stored in the file: the reference's loader takes it as a template argument); all parts in turn give
+ * loadUnifiedMesh.                                                                                                      */
+typedef struct
+{
+    size_t          n;
+    const uint64_t* nodes; /* [n][(order+1)^d] global node ids, element-local lexicographic order                       */
+    const double*   verts; /* [n][2^d][3]                                                                                */
+    const uint64_t* ids;   /* [n] element ids (unique over the whole mesh, boundary elements included)                   */
+} l3k_meshfile_elems;
+typedef struct
+{
+    uint16_t           id; /* d_id_t (common/Typedefs.hpp)                                                               */
+    l3k_meshfile_elems hex, quad, line;
+} l3k_meshfile_domain;
+typedef struct
+{
+    int                        order;
+    size_t                     n_domains;
+    const l3k_meshfile_domain* domains;
+    uint64_t                   nodes_begin;   /* first owned global node id (0 if none owned, MeshUtils.hpp:327)        */
+    size_t                     n_owned_nodes;
+    size_t                     n_boundary_ids;
+    const uint16_t*            boundary_ids;
+} l3k_meshfile_part_desc;
+typedef struct l3k_meshfile_part l3k_meshfile_part;
+int l3k_meshfile_part_bytes(const l3k_meshfile_part_desc* desc, size_t* bytes);
+int l3k_meshfile_save(const char* path, const char* comment, size_t n_parts, const size_t* part_bytes, size_t part,
+                      const l3k_meshfile_part_desc* desc, int write_header);
+int l3k_meshfile_info(const char* path, size_t* n_parts, size_t* part_bytes, size_t capacity);
+int l3k_meshfile_load(const char* path, size_t part, int order, l3k_meshfile_part** out);
+int l3k_meshfile_part_get(const l3k_meshfile_part* part, l3k_meshfile_part_desc* out); /* pointers live as long as part */
+int l3k_meshfile_part_destroy(l3k_meshfile_part* part);
 
 #ifdef __cplusplus
 }

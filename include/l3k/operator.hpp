@@ -338,5 +338,36 @@ inline std::vector< double > loadResults(const char* path, size_t field, std::sp
     check(l3k_results_load(path, field, int64_t(node_ids.size()), node_ids.data(), 0, out.data()));
     return out;
 }
+
+// save(comm, mesh, path, comment) / loadPartitionedMesh of post/NativeIO.hpp:75-108, :219-232 for this rank's part; the
+// sizes of all parts are gathered by the caller (the reference: comm.gather at :83)
+inline size_t meshFilePartBytes(const l3k_meshfile_part_desc& desc)
+{
+    size_t bytes = 0;
+    check(l3k_meshfile_part_bytes(&desc, &bytes));
+    return bytes;
+}
+inline void saveMesh(const char* path, const char* comment, std::span< const size_t > part_bytes, size_t part,
+                     const l3k_meshfile_part_desc& desc)
+{
+    check(l3k_meshfile_save(path, comment, part_bytes.size(), part_bytes.data(), part, &desc, part == 0 ? 1 : 0));
+}
+class LoadedMeshPart
+{
+public:
+    LoadedMeshPart(const char* path, size_t part, int order) { check(l3k_meshfile_load(path, part, order, &m_part)); }
+    ~LoadedMeshPart() { l3k_meshfile_part_destroy(m_part); }
+    LoadedMeshPart(const LoadedMeshPart&)            = delete;
+    LoadedMeshPart& operator=(const LoadedMeshPart&) = delete;
+    l3k_meshfile_part_desc get() const // the arrays live as long as this object
+    {
+        l3k_meshfile_part_desc d{};
+        check(l3k_meshfile_part_get(m_part, &d));
+        return d;
+    }
+
+private:
+    l3k_meshfile_part* m_part = nullptr;
+};
 } // namespace l3k
 #endif

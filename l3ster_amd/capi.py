@@ -46,7 +46,25 @@ class HostMeshView(C.Structure):
                 ("n_global_nodes", C.c_int64), ("elem_nodes", c_uint32_p), ("elem_verts", c_double_p),
                 ("node_grid_id", c_int64_p), ("node_boundary", c_uint8_p), ("n_nbrs", C.c_int), ("nbr_rank", c_int_p),
                 ("send_offsets", c_int64_p), ("send_nodes", c_int32_p), ("ghost_offsets", c_int64_p),
-                ("elem_boundary", c_uint8_p)]
+                ("elem_boundary", c_uint8_p), ("ghost_global_id", c_int64_p)]
+
+
+c_uint64_p = C.POINTER(C.c_uint64)
+c_uint16_p = C.POINTER(C.c_uint16)
+
+
+class MeshFileElems(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("nodes", c_uint64_p), ("verts", c_double_p), ("ids", c_uint64_p)]
+
+
+class MeshFileDomain(C.Structure):
+    _fields_ = [("id", C.c_uint16), ("hex", MeshFileElems), ("quad", MeshFileElems), ("line", MeshFileElems)]
+
+
+class MeshFilePartDesc(C.Structure):
+    _fields_ = [("order", C.c_int), ("n_domains", C.c_size_t), ("domains", C.POINTER(MeshFileDomain)),
+                ("nodes_begin", C.c_uint64), ("n_owned_nodes", C.c_size_t), ("n_boundary_ids", C.c_size_t),
+                ("boundary_ids", c_uint16_p)]
 
 
 # every symbol include/l3k.h declares: (name, restype, argtypes)
@@ -129,6 +147,13 @@ SIGNATURES = {
                                    C.c_int]),
     "l3k_results_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "l3k_results_load": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int64, c_int64_p, C.c_int64, c_double_p]),
+    "l3k_meshfile_part_bytes": (C.c_int, [C.POINTER(MeshFilePartDesc), C.POINTER(C.c_size_t)]),
+    "l3k_meshfile_save": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_size_t,
+                                    C.POINTER(MeshFilePartDesc), C.c_int]),
+    "l3k_meshfile_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t]),
+    "l3k_meshfile_load": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(_vp)]),
+    "l3k_meshfile_part_get": (C.c_int, [_vp, C.POINTER(MeshFilePartDesc)]),
+    "l3k_meshfile_part_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -222,7 +222,7 @@ struct l3k_hostmesh
     i64                     n_elems = 0, n_interior = 0, n_owned = 0, n_ghost = 0, base = 0, n_global = 0;
     std::vector< uint32_t > elem_nodes;
     std::vector< double >   elem_verts;
-    std::vector< i64 >      node_grid_id;
+    std::vector< i64 >      node_grid_id, ghost_global_id;
     std::vector< uint8_t >  node_boundary;
     std::vector< uint8_t >  elem_boundary;
     std::vector< int >      nbr_rank;
@@ -312,6 +312,9 @@ extern "C" int l3k_cube_partition_create(const int ne[3], int order, const int p
     }
     std::sort(ghosts.begin(), ghosts.end(), [](const Ghost& a, const Ghost& b) { return a.global_id < b.global_id; });
     hm->n_ghost = static_cast< i64 >(ghosts.size());
+    hm->ghost_global_id.reserve(ghosts.size());
+    for (const auto& g : ghosts)
+        hm->ghost_global_id.push_back(g.global_id);
     if (hm->n_owned + hm->n_ghost >= (i64(1) << 32))
     {
         setError("partition has more than 2^32 local nodes");
@@ -506,5 +509,6 @@ extern "C" int l3k_hostmesh_view_get(const l3k_hostmesh* hm, l3k_hostmesh_view* 
     v->send_offsets     = hm->send_offsets.data();
     v->send_nodes       = hm->send_nodes.data();
     v->ghost_offsets    = hm->ghost_offsets.data();
+    v->ghost_global_id  = hm->ghost_global_id.data();
     return 0;
 }

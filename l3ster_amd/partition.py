@@ -48,6 +48,7 @@ class PartitionedMesh:
         touched = torch.unique(E)
         ghosts = touched[(touched < b0) | (touched >= b1)]  # sorted by global id
         self.n_ghost_nodes = int(ghosts.numel())
+        self.ghost_global_id = ghosts.cpu().numpy()
         # local ids: owned = gid - base, ghosts behind them in global-id order
         is_owned = (E >= b0) & (E < b1)
         local = torch.where(is_owned, E - b0, self.n_owned_nodes + torch.searchsorted(ghosts, E))
@@ -70,11 +71,13 @@ class PartitionedMesh:
         pairs = torch.unique(torch.stack([q_of, en_o[sel] - b0], dim=1), dim=0).cpu().numpy() if bool(sel.any()) else np.zeros((0, 2), np.int64)
         nbrs = sorted(set(ghost_owner.tolist()) | set(pairs[:, 0].tolist()))
         self.nbr_rank, self.send_nodes, self.ghost_ranges = [], [], []
+        cursor = 0
         for q in nbrs:
             self.nbr_rank.append(int(q))
             self.send_nodes.append(pairs[pairs[:, 0] == q, 1].astype(np.int32))
-            g = np.nonzero(ghost_owner == q)[0]
-            self.ghost_ranges.append((int(g[0]), int(g[-1]) + 1) if g.size else (0, 0))
+            n_from_q = int(np.count_nonzero(ghost_owner == q))
+            self.ghost_ranges.append((cursor, cursor + n_from_q))  # global ids are rank-major: the ranges tile the ghosts
+            cursor += n_from_q
 
     n_local_nodes = system.CubePartition.n_local_nodes
     node_coords = system.CubePartition.node_coords

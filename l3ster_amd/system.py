@@ -108,6 +108,7 @@ class CubePartition:
             self.node_grid_id = as_np(v.node_grid_id, (nl,))
             self.node_boundary = as_np(v.node_boundary, (nl,))
             self.elem_boundary = as_np(v.elem_boundary, (v.n_elems,))
+            self.ghost_global_id = as_np(v.ghost_global_id, (v.n_ghost_nodes,))
             nn = v.n_nbrs
             self.nbr_rank = [v.nbr_rank[i] for i in range(nn)]
             so = [v.send_offsets[i] for i in range(nn + 1)]

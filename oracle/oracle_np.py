@@ -261,6 +261,121 @@ def results_file_parse(data):
     return lines[2][3:].decode(), vals
 
 
+# ---- native mesh file: restatement of post/NativeIO.hpp:75-108 (writer), :161-182 (header), mesh/MeshUtils.hpp:318-360
+# (serializeMesh / deserializeMesh) and util/Serialization.hpp:20-66 (object representation / count + values / members in
+# order).  The reference holds no mesh file among its test data: the format is pinned by reading the source only.
+_MESH_DIMS = (3, 2, 1)  # Hex, Quad, Line: the order of mesh/ElementType.hpp:11-16 in every domain's element tuple
+
+
+def mesh_part_bytes(order, domains, nodes_begin, n_owned, boundary_ids):
+    """domains: {id: [hex, quad, line]} with each entry None or (nodes [n][(p+1)^d] u64, verts [n][2^d][3] f64, ids [n]
+    u64).  An element is its object representation {nodes; vertices; id} (mesh/Element.hpp:29-31), no padding."""
+    out = [np.uint64(len(domains)).tobytes()]
+    for dom_id in sorted(domains):  # std::map< d_id_t, Domain > (MeshPartition.hpp:49)
+        out.append(np.uint16(dom_id).tobytes())  # pair.first, 2 bytes, the pair is serialised member by member
+        for dim, el in zip(_MESH_DIMS, domains[dom_id]):
+            n = 0 if el is None else len(el[2])
+            out.append(np.uint64(n).tobytes())
+            for i in range(n):
+                out.append(np.asarray(el[0][i], dtype=np.uint64).reshape((order + 1) ** dim).tobytes())
+                out.append(np.asarray(el[1][i], dtype=np.float64).reshape(2 ** dim * 3).tobytes())
+                out.append(np.uint64(el[2][i]).tobytes())
+    out.append(np.uint64(nodes_begin).tobytes())
+    out.append(np.uint64(n_owned).tobytes())
+    b = np.asarray(boundary_ids, dtype=np.uint16)
+    out.append(np.uint64(b.size).tobytes() + b.tobytes())
+    return b"".join(out)
+
+
+def mesh_file_bytes(parts, comment=""):
+    """The whole file for the serialised parts (bytes each)."""
+    header = ("L3STER mesh file\nv1.0\n// %s\n" % comment.replace("\n", " ")).encode()  # :91-92
+    header += np.array([len(parts)] + [len(p) for p in parts], dtype=np.uint64).tobytes()  # :94-96
+    return header + b"".join(parts)  # part r at header + sum of the sizes before it (:100-101)
+
+
+def mesh_file_parse(data, order):
+    """extractSavedPartitionInfo + deserializeMesh of every part.  Returns (comment, [(domains, nodes_begin, n_owned,
+    boundary_ids)])."""
+    pos, lines = 0, []
+    for _ in range(3):
+        nl = data.index(b"\n", pos)
+        lines.append(data[pos:nl])
+        pos = nl + 1
+    assert lines[0] == b"L3STER mesh file" and lines[1] == b"v1.0" and lines[2].startswith(b"// ")
+    u64 = lambda at: int(np.frombuffer(data[at:at + 8], dtype=np.uint64)[0])
+    n_parts = u64(pos)
+    sizes = [u64(pos + 8 + 8 * i) for i in range(n_parts)]
+    pos += 8 + 8 * n_parts
+    parts = []
+    for sz in sizes:
+        end, q = pos + sz, pos
+        doms = {}
+        n_dom = u64(q)
+        q += 8
+        for _ in range(n_dom):
+            dom_id = int(np.frombuffer(data[q:q + 2], dtype=np.uint16)[0])
+            q += 2
+            els = []
+            for dim in _MESH_DIMS:
+                n = u64(q)
+                q += 8
+                nn, nv = (order + 1) ** dim, 2 ** dim
+                rec = np.frombuffer(data[q:q + n * 8 * (nn + 3 * nv + 1)], dtype=np.uint64).reshape(n, nn + 3 * nv + 1)
+                q += rec.nbytes
+                els.append((rec[:, :nn].copy(), rec[:, nn:nn + 3 * nv].copy().view(np.float64).reshape(n, nv, 3),
+                            rec[:, -1].copy()) if n else None)
+            doms[dom_id] = els
+        nodes_begin, n_owned, nb = u64(q), u64(q + 8), u64(q + 16)
+        bnd = np.frombuffer(data[q + 24:q + 24 + 2 * nb], dtype=np.uint16).copy()
+        assert q + 24 + 2 * nb == end
+        parts.append((doms, nodes_begin, n_owned, bnd))
+        pos = end
+    return lines[2][3:].decode(), parts
+
+
+def make_cube_mesh(dist):
+    """makeCubeMesh(dist) (mesh/primitives/CubeMesh.hpp:16-138) as mesh-file domains: order-1 hexes of domain 0 and the
+    boundary quads of domains 1..6 (back z0, front z1, bottom y0, top y1, left x0, right x1), node ids x fastest, element
+    ids in emplacement order.  Returns (domains, n_nodes)."""
+    d = np.asarray(dist, dtype=np.float64)
+    n = d.size
+    e = n - 1
+    doms = {k: ([], [], []) for k in range(7)}
+    nid = lambda ix, iy, iz: n * n * iz + n * iy + ix
+    pt = lambda ix, iy, iz: (d[ix], d[iy], d[iz])
+    el = 0
+
+    def emplace(dom, corners):
+        nonlocal el
+        doms[dom][0].append([nid(*c) for c in corners])
+        doms[dom][1].append([pt(*c) for c in corners])
+        doms[dom][2].append(el)
+        el += 1
+
+    for iz in range(e):
+        for iy in range(e):
+            for ix in range(e):
+                emplace(0, [(ix + a, iy + b, iz + c) for c in (0, 1) for b in (0, 1) for a in (0, 1)])  # :44-61
+    for iy in range(e):
+        for ix in range(e):
+            for dom, z in ((1, 0), (2, e)):  # :70-90: back, front
+                emplace(dom, [(ix + a, iy + b, z) for b in (0, 1) for a in (0, 1)])
+    for iz in range(e):
+        for ix in range(e):
+            for dom, y in ((3, 0), (4, e)):  # :95-113: bottom, top
+                emplace(dom, [(ix + a, y, iz + c) for c in (0, 1) for a in (0, 1)])
+    for iz in range(e):
+        for iy in range(e):
+            for dom, x in ((5, 0), (6, e)):  # :118-136: left, right
+                emplace(dom, [(x, iy + b, iz + c) for c in (0, 1) for b in (0, 1)])
+    out = {}
+    for k, (nodes, verts, ids) in doms.items():
+        el_k = (np.array(nodes, dtype=np.uint64), np.array(verts, dtype=np.float64), np.array(ids, dtype=np.uint64))
+        out[k] = [el_k, None, None] if k == 0 else [None, el_k, None]
+    return out, n ** 3
+
+
 # ---- order elevation of an order-1 hex mesh: restatement of the SPECIFICATION in l3ster_amd/csrc/api_mesh.hip -----------
 # (the reference's convertMeshToOrder, mesh/ConvertMeshToOrder.hpp:51-104, numbers by traversal order; what it and this
 # share -- and what tests/MeshTests.cpp:244-279 checks -- is the topology: one node per vertex, p-1 per edge, (p-1)^2 per
