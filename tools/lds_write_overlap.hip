@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void k(double* out, long long* clk, int iters,
 #pragma unroll
         for (int w = 0; w < 7; ++w)
         {
-            if constexpr (MODE != 1)
+            if constexpr (MODE != 1 && MODE < 5)
             {
 #pragma unroll
                 for (int c = 0; c < 10; ++c)
@@ -42,6 +42,52 @@ __global__ __launch_bounds__(512) void k(double* out, long long* clk, int iters,
             }
             if constexpr (MODE == 3)
                 asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(p), "v"(d2{acc[w], acc[w + 1]}), "n"(w * 1024) : "memory");
+        }
+        if constexpr (MODE == 5) // the same bytes as 7 ds_write_b128 in 14 ds_write_b64 (conflict-free: 512 B per wave-instruction)
+        {
+            const unsigned p8 = (threadIdx.x & 63) * 8 + (threadIdx.x >> 6) * 8192;
+#pragma unroll
+            for (int w = 0; w < 14; ++w)
+                asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(p8), "v"(acc[w % 8]), "n"(w * 512) : "memory");
+        }
+        if constexpr (MODE == 6) // ... in 7 ds_write2_b64 (two 8-byte values per lane at two offsets 512 B apart)
+        {
+            const unsigned p8 = (threadIdx.x & 63) * 8 + (threadIdx.x >> 6) * 8192;
+#pragma unroll
+            for (int w = 0; w < 7; ++w)
+                asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:64" : : "v"(p8 + w * 1024), "v"(acc[w]), "v"(acc[w + 1]) : "memory");
+        }
+        if constexpr (MODE == 7) // 7 ds_write_b128 by 49 of the 64 lanes (the element kernel's sweeps)
+        {
+            if ((threadIdx.x & 63) < 49)
+            {
+#pragma unroll
+                for (int w = 0; w < 7; ++w)
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(p), "v"(d2{acc[w], acc[w + 1]}), "n"(w * 1024) : "memory");
+            }
+        }
+        if constexpr (MODE == 8) // 14 ds_read_b64 + wait
+        {
+            const unsigned p8 = (threadIdx.x & 63) * 8 + (threadIdx.x >> 6) * 8192;
+            double         r[14];
+#pragma unroll
+            for (int w = 0; w < 14; ++w)
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[w]) : "v"(p8), "n"(w * 512));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int w = 0; w < 7; ++w)
+                acc[w] += r[w] + r[w + 7];
+        }
+        if constexpr (MODE == 9) // 7 ds_read_b128 + wait, no FMAs
+        {
+            d2 r[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[w]) : "v"(p), "n"(w * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int w = 0; w < 7; ++w)
+                acc[w] += r[w].x;
         }
         if constexpr (MODE == 1 || MODE == 2)
         {
@@ -107,6 +153,11 @@ int main()
     run< 1 >("7 ds_write_b128", out, clk, cus);
     run< 2 >("70 v_fma_f64, then 7 ds_write_b128", out, clk, cus);
     run< 3 >("(10 v_fma_f64, 1 ds_write_b128) x 7", out, clk, cus);
+    run< 5 >("14 ds_write_b64 (same bytes)", out, clk, cus);
+    run< 6 >("7 ds_write2_b64 (same bytes)", out, clk, cus);
+    run< 7 >("7 ds_write_b128, 49 lanes", out, clk, cus);
+    run< 9 >("7 ds_read_b128, wait", out, clk, cus);
+    run< 8 >("14 ds_read_b64, wait", out, clk, cus);
     run< 4 >("7 ds_read_b128, wait, 77 VALU", out, clk, cus);
     return 0;
 }
