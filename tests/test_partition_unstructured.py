@@ -123,12 +123,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, p, out_dir):
+def _part_vector_with_empty_rank(ev, world, empty_rank):
+    """part_vector over world - 1 parts, numbered around a rank that gets no element (the reference's EmptyPartitionTest: np = 4
+    with empty ranks)."""
+    if empty_rank < 0:
+        return part_vector(ev, world)
+    pv = part_vector(ev, world - 1)
+    return pv + (pv >= empty_rank)
+
+
+def _worker(rank, world, port, p, out_dir, empty_rank=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         en, ev, n_nonint = small_mesh(p, n_keep=240)
-        m = partition.PartitionedMesh(en, ev, n_nonint, part_vector(ev, world), rank, world, p)
+        m = partition.PartitionedMesh(en, ev, n_nonint, _part_vector_with_empty_rank(ev, world, empty_rank), rank, world, p)
+        if rank == empty_rank:
+            assert m.n_elems == 0 and m.n_owned_nodes == 0 and m.n_ghost_nodes == 0 and m.nbr_rank == []
         mask = dirichlet_mask_of(m, ev[..., 0].max())
         be = OracleBackend(m, system.KERNEL_DIFFUSION3D, p + 1, U, mask, kparams=[0.7, 1.0])
         op = DistributedOperator(be, HaloPlan(m, U, "cpu"))
@@ -143,9 +154,11 @@ def _worker(rank, world, port, p, out_dir):
         dist.destroy_process_group()
 
 
-def test_partitioned_apply_equals_single_rank_gloo(tmp_path):
-    world, p = 3, 2
-    mp.spawn(_worker, args=(world, _free_port(), p, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,empty_rank", [(3, -1), (4, 2), (4, 0)])
+def test_partitioned_apply_equals_single_rank_gloo(tmp_path, world, empty_rank):
+    """(empty_rank >= 0: one rank owns no element and no node -- tests/EmptyPartitionTest.cpp of the reference)"""
+    p = 2
+    mp.spawn(_worker, args=(world, _free_port(), p, str(tmp_path), empty_rank), nprocs=world, join=True)
     en, ev, n_nonint = small_mesh(p, n_keep=240)
     whole = partition.PartitionedMesh(en, ev, n_nonint, np.zeros(en.shape[0], int), 0, 1, p)
     mask = dirichlet_mask_of(whole, ev[..., 0].max())
@@ -155,7 +168,10 @@ def test_partitioned_apply_equals_single_rank_gloo(tmp_path):
     row_of = {int(g): i for i, g in enumerate(whole.node_grid_id)}
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        rows = np.array([row_of[int(g)] for g in d["gid"]])
+        rows = np.array([row_of[int(g)] for g in d["gid"]], dtype=np.int64)
+        if r == empty_rank:
+            assert rows.size == 0 and d["y"].size == 0
+            continue
         ref = y_ref.reshape(whole.n_local_nodes, U)[rows]
         assert rel_err(d["y"].reshape(-1, U), ref) < 1e-12
 
