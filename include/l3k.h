@@ -103,7 +103,8 @@ int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream);
  * and PCG iteration counts move with them; for parity runs this build can fix the order instead: meshes created while the
  * mode is on carry a colouring of their elements (no two elements of a colour share a node) and every domain-kernel
  * launch (apply, diag / rhs) goes colour by colour, so each row receives its contributions in a fixed order; <p, A p>
- * comes from the fixed-order dot product.  Slower (one launch per colour); boundary terms are not covered (error). */
+ * comes from the fixed-order dot product.  Boundary terms created while the mode is on colour their element sides the
+ * same way and launch per colour behind the domain kernel.  Slower (one launch per colour). */
 int l3k_ctx_set_deterministic(l3k_ctx* ctx, int on);
 int l3k_ctx_synchronize(l3k_ctx* ctx);
 int l3k_ctx_destroy(l3k_ctx* ctx);

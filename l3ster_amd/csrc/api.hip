@@ -314,6 +314,31 @@ int bndArgs(const l3k_bnd* b, int which, int ncols, l3k::dev::ElemArgs& a)
     }
     return 0;
 }
+// the launch ranges of a side call: the caller's range, or in deterministic mode one launch per colour of the classes it
+// covers (sides of one colour share no node: the order of the additions to a row is the order of the launches)
+template < typename F >
+int forEachSideRange(const l3k_bnd* b, int which, l3k::dev::ElemArgs& a, F&& launch)
+{
+    if (!b->ctx->deterministic)
+        return launch(a);
+    if (b->det_ptr[0].empty())
+    {
+        setError("deterministic mode was enabled after this boundary term was created: create it with the mode on");
+        return -1;
+    }
+    const bool classes[2] = {which == 0 || which == 2, which == 1 || which == 2};
+    for (int cls = 0; cls < 2; ++cls)
+        if (classes[cls])
+            for (size_t c = 0; c + 1 < b->det_ptr[cls].size(); ++c)
+            {
+                a.face_begin = b->det_ptr[cls][c];
+                a.face_count = b->det_ptr[cls][c + 1] - b->det_ptr[cls][c];
+                if (a.face_count > 0)
+                    if (int rc = launch(a))
+                        return rc;
+            }
+    return 0;
+}
 const l3k::dev::BoundaryInstance* bndInstance(const l3k_bnd* b, int ncols)
 {
     const auto* inst = l3k::dev::findBoundaryInstance(b->kernel_id, b->mesh->order, b->nq, ncols);
@@ -346,7 +371,7 @@ int bndApplyImpl(l3k_bnd* b, int which, const double* d_x, size_t ldx, const dou
     const auto* inst = bndInstance(b, ncols);
     if (!inst)
         return -4;
-    return inst->apply(a, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream);
+    return forEachSideRange(b, which, a, [&](l3k::dev::ElemArgs& r) { return inst->apply(r, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream); });
 }
 int bndDiagRhsImpl(l3k_bnd* b, int which, const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs,
                    size_t ldr, double* d_diag_ghost, double* d_rhs_ghost, size_t ldrg)
@@ -366,7 +391,7 @@ int bndDiagRhsImpl(l3k_bnd* b, int which, const double* d_dirichlet_vals, size_t
     const auto* inst = bndInstance(b, b->n_rhs);
     if (!inst)
         return -4;
-    return inst->diag_rhs(a, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream);
+    return forEachSideRange(b, which, a, [&](l3k::dev::ElemArgs& r) { return inst->diag_rhs(r, b->blob.empty() ? nullptr : b->blob.data(), b->ctx->stream); });
 }
 } // namespace
 
@@ -410,6 +435,10 @@ int buildDeterministicPlan(l3k_mesh& m, const l3k_mesh_desc* d, const std::vecto
         for (int v = 0; v < 8; ++v)
             used[d->elem_nodes[e * N + corner[v]]] |= uint64_t(1) << c;
     }
+    m.det_corner_nodes.resize(static_cast< size_t >(d->n_elems) * 8);
+    for (int64_t e = 0; e < d->n_elems; ++e)
+        for (int v = 0; v < 8; ++v)
+            m.det_corner_nodes[size_t(e) * 8 + v] = d->elem_nodes[e * N + corner[v]];
     std::vector< int64_t > order(static_cast< size_t >(d->n_elems));
     for (int64_t e = 0; e < d->n_elems; ++e)
         order[e] = e;
@@ -1025,11 +1054,6 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
     a.fuse_beta = mf->fuse;
     const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
     const auto* inst = l3k::dev::findInstance(mf->kernel_id, mf->mesh->order, mf->nq, ncols);
-    if (mf->ctx->deterministic && !mf->boundary_terms.empty())
-    {
-        setError("deterministic mode covers the domain kernels only: this system has boundary terms attached (atomic scatter)");
-        return -1;
-    }
     if (inst)
     {
         if (int rc = forEachLaunchRange(mf, which, a, [&](l3k::dev::ElemArgs& r) { return inst->apply(r, blob, mf->ctx->stream); }))
@@ -1224,11 +1248,6 @@ int l3k_mf_diag_rhs(l3k_mf* mf, int which, const double* d_dirichlet_vals, size_
     const auto* inst = instanceFor(mf, mf->n_rhs);
     if (!inst)
         return -4;
-    if (mf->ctx->deterministic && !mf->boundary_terms.empty())
-    {
-        setError("deterministic mode covers the domain kernels only: this system has boundary terms attached (atomic scatter)");
-        return -1;
-    }
     if (int rc = forEachLaunchRange(mf, which, a, [&](l3k::dev::ElemArgs& r) {
             return inst->diag_rhs(r, mf->blob.empty() ? nullptr : mf->blob.data(), mf->ctx->stream);
         }))
@@ -1403,6 +1422,66 @@ int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpar
             b->n_interior_faces = int64_t(fe.size());
     }
     b->n_faces = n_faces;
+    if (ctx->deterministic)
+    {
+        // greedy colouring of the sides by their four corner nodes (two sides of a conforming mesh that share a node share
+        // a corner), class by class; the lists are stored in (class, colour) order
+        if (!mesh->det_built)
+        {
+            setError("deterministic mode was enabled after this mesh was created: create the mesh with the mode on");
+            return -1;
+        }
+        static constexpr int side_corners[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 4, 5}, {2, 3, 6, 7}, {0, 2, 4, 6}, {1, 3, 5, 7}};
+        std::unordered_map< uint32_t, uint64_t > used;
+        std::vector< uint8_t >                   colour(fe.size());
+        int                                      n_colours = 0;
+        for (size_t i = 0; i < fe.size(); ++i)
+        {
+            uint64_t taken = 0;
+            for (int v = 0; v < 4; ++v)
+            {
+                const auto it = used.find(mesh->det_corner_nodes[size_t(fe[i]) * 8 + side_corners[fs[i]][v]]);
+                if (it != used.end())
+                    taken |= it->second;
+            }
+            int c = 0;
+            while (c < 64 && ((taken >> c) & 1u))
+                ++c;
+            if (c == 64)
+            {
+                setError("deterministic mode: more than 64 colours needed for the boundary sides");
+                return -1;
+            }
+            colour[i] = uint8_t(c);
+            n_colours = std::max(n_colours, c + 1);
+            for (int v = 0; v < 4; ++v)
+                used[mesh->det_corner_nodes[size_t(fe[i]) * 8 + side_corners[fs[i]][v]]] |= uint64_t(1) << c;
+        }
+        std::vector< size_t > order(fe.size());
+        for (size_t i = 0; i < order.size(); ++i)
+            order[i] = i;
+        auto by_colour = [&](size_t x, size_t y) { return colour[x] < colour[y]; };
+        std::stable_sort(order.begin(), order.begin() + b->n_interior_faces, by_colour);
+        std::stable_sort(order.begin() + b->n_interior_faces, order.end(), by_colour);
+        std::vector< int64_t > fe2(fe.size());
+        std::vector< uint8_t > fs2(fs.size());
+        for (size_t i = 0; i < order.size(); ++i)
+            fe2[i] = fe[order[i]], fs2[i] = fs[order[i]];
+        for (int cls = 0; cls < 2; ++cls)
+        {
+            const int64_t lo = cls ? b->n_interior_faces : 0, hi = cls ? n_faces : b->n_interior_faces;
+            b->det_ptr[cls].assign(static_cast< size_t >(n_colours) + 1, hi);
+            int64_t i = lo;
+            for (int c = 0; c < n_colours; ++c)
+            {
+                b->det_ptr[cls][c] = i;
+                while (i < hi && colour[order[size_t(i)]] == c)
+                    ++i;
+            }
+        }
+        fe.swap(fe2);
+        fs.swap(fs2);
+    }
     L3K_HIP(hipSetDevice(ctx->device));
     const auto block = l3k::host::deviceTableBlock(mesh->order, b->nq);
     if (int rc = b->tables.upload(block.data(), block.size(), ctx->stream))

@@ -144,6 +144,7 @@ struct l3k_mesh
     DevBuf< double >       det_elem_verts;
     DevBuf< uint8_t >      det_elem_flags;
     std::vector< int64_t > det_ptr[2];
+    std::vector< uint32_t > det_corner_nodes; // host, [n_elems][8] in the ORIGINAL element order: colouring of boundary sides
     int64_t nOwnedDofs() const { return n_owned_nodes * dofs_per_node; }
     int64_t nLocalDofs() const { return (n_owned_nodes + n_ghost_nodes) * dofs_per_node; }
 };
@@ -188,6 +189,9 @@ struct l3k_bnd
     DevBuf< int64_t >     face_elem; // sides of interior elements first
     DevBuf< uint8_t >     face_side;
     int64_t               n_faces = 0, n_interior_faces = 0;
+    // deterministic mode: the two classes of sides sorted by colour (sides of one colour share no node); det_ptr[cls][c] ..
+    // det_ptr[cls][c + 1] = positions of colour c in face_elem / face_side
+    std::vector< int64_t > det_ptr[2];
     const double*         fields = nullptr;
     size_t                ldf    = 0;
     double                time   = 0.;

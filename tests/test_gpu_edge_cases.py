@@ -241,3 +241,43 @@ def test_deterministic_mode_is_bitwise_reproducible(p, ne):
     for r in runs[1:]:
         assert r[0] == runs[0][0]
         assert torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and torch.equal(r[3], runs[0][3])
+
+
+def test_deterministic_mode_with_boundary_terms():
+    """Boundary equation kernels in deterministic mode: the element sides are coloured like the elements (sides of one colour
+    share no node) and launched colour by colour behind the domain kernel.  Applies and diag / rhs of a system with an
+    attached boundary term are bitwise equal run to run and agree with the oracle."""
+    import torch
+    import oracle_lib as O
+    from helpers import oracle_mesh, rel_err
+    from l3ster_amd import system
+    torch.cuda.set_device(0)
+    p, ne, U, kid, kpar = 2, 5, 4, system.KERNEL_DIFFUSION3D, [1.0, 1.0]
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = part.dirichlet_mask(U, sides=(4, 5))
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_deterministic(True)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar)
+    fe, fs = part.boundary_sides([0, 1, 2, 3])  # four walls: sides of corner elements share edges
+    mf.attach_boundary(system.BoundaryTerm(mesh, system.KERNEL_ADIABATIC3D, fe, fs))
+    x = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=3)
+    ys, drs = [], []
+    for _ in range(3):
+        y = torch.full_like(x, 0.25)
+        mf.apply(x, y, 1.5, -0.5)
+        ys.append(y)
+        drs.append(tuple(t.clone() for t in mf.diag_rhs(None)))
+    torch.cuda.synchronize()
+    for k in (1, 2):
+        assert torch.equal(ys[0], ys[k]) and torch.equal(drs[0][0], drs[k][0]) and torch.equal(drs[0][1], drs[k][1])
+    om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
+    xh = x.cpu().numpy()
+    want = O.mf_apply(om, kid, xh.T, np.full((xh.shape[1], 1), 0.25, order="F"), alpha=1.5, beta=-0.5, kparams=kpar)
+    O.bnd_apply(om, O.KERNEL_ADIABATIC3D, fe, fs, np.asfortranarray(xh.T), want, alpha=1.5)
+    assert rel_err(ys[0].cpu().numpy().T, want) < 1e-12
+    wd, wr = O.mf_diag_rhs(om, kid, kparams=kpar, finalize=False)
+    O.bnd_diag_rhs(om, O.KERNEL_ADIABATIC3D, fe, fs, wd, wr)
+    wd[mask != 0] = 1.0
+    wr[mask != 0] = 0.0
+    assert rel_err(drs[0][0].cpu().numpy(), wd) < 1e-12 and rel_err(drs[0][1].cpu().numpy().T, wr) < 1e-11
