@@ -1066,6 +1066,17 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         inst = instanceFor(mf, 1);
         if (!inst)
             return -4;
+        if (inst->apply_cols && mf->dense && !mf->ctx->deterministic && std::getenv("L3K_COLUMN_BY_COLUMN") == nullptr) // (the switch: cross-check)
+        {
+            // dense dof layout: all columns in one pass over the elements (node ids, flags and the work ticket once per
+            // element), MatrixFreeSystem.hpp:678-688
+            l3k::dev::ElemArgs ac = a;
+            ac.n_cols             = ncols;
+            ac.energy             = nullptr;
+            if (int rc = inst->apply_cols(ac, blob, mf->ctx->stream))
+                return rc;
+        }
+        else
         for (int c = 0; c < ncols; ++c)
         {
             l3k::dev::ElemArgs ac = a;

@@ -90,6 +90,7 @@ struct ElemArgs
     int64_t elem_begin_out; // output slot of the first element of the batch
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     all_affine; // every element of the mesh is a parallelepiped (one Jacobian per element)
+    int     n_cols;     // single-wave kernel, multi-column variant: columns applied per element pass (0 / 1: one)
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
     long long* stamps; // L3K_ABLATION builds with env L3K_STAMPS: per-stage cycle counters of workgroup 0 ([iteration][16])
@@ -112,6 +113,7 @@ struct Instance
     LaunchFn diag_rhs;
     LaunchFn assemble;
     size_t   assemble_ws_doubles; // workspace doubles per element for `assemble`
+    LaunchFn apply_cols = nullptr; // ncols == 1 instances: applies a.n_cols columns in one pass over the elements, or nullptr
 };
 
 // boundary equation kernel on element sides (device/boundary.hpp)

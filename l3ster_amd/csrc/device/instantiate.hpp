@@ -44,17 +44,35 @@ int launchColumnsFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
 {
     if (!a.dense)
         return launchSumfactApply< T, P, NQ, R, false >(a, kparam_blob, stream);
-    for (int c = 0; c < R; ++c)
+    if constexpr (FastCfg< T, P, NQ >::multi_column)
     {
-        ElemArgs ac = a;
-        ac.x        = a.x + a.ldx * c;
-        ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
-        ac.y        = a.y + a.ldy * c;
-        ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
-        if (int rc = launchSumfactFast< T, P, NQ >(ac, kparam_blob, stream))
-            return rc;
+        ElemArgs ac = a; // all R columns in one pass over the elements (the multi-column variant of the single-wave kernel)
+        ac.n_cols   = R;
+        return launchSumfactFastCols< T, P, NQ >(ac, kparam_blob, stream);
     }
-    return 0;
+    else
+    {
+        for (int c = 0; c < R; ++c)
+        {
+            ElemArgs ac = a;
+            ac.x        = a.x + a.ldx * c;
+            ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
+            ac.y        = a.y + a.ldy * c;
+            ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
+            if (int rc = launchSumfactFast< T, P, NQ >(ac, kparam_blob, stream))
+                return rc;
+        }
+        return 0;
+    }
+}
+// the column-loop entry of a single-column instance (Instance::apply_cols), or nullptr where the single-wave kernel does not fit
+template < typename T, int P, int NQ, int R >
+constexpr LaunchFn selectApplyCols()
+{
+    if constexpr (R == 1 && FastCfg< T, P, NQ >::feasible && FastCfg< T, P, NQ >::multi_column)
+        return &launchSumfactFastCols< T, P, NQ >;
+    else
+        return nullptr;
 }
 // applies use the register-resident pipelined kernel when its working set fits
 template < typename T, int P, int NQ, int R >
@@ -80,7 +98,8 @@ constexpr LaunchFn selectApply()
                                           ::l3k::dev::selectApply< T, P, NQ, R >(),                                  \
                                           &::l3k::dev::launchDiagRhs< T, P, NQ, R >,                               \
                                           &::l3k::dev::launchAssemble< T, P, NQ >,                                 \
-                                          ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >()});             \
+                                          ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >(),               \
+                                          ::l3k::dev::selectApplyCols< T, P, NQ, R >()});                            \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
     }

@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 #include <type_traits>
 
 namespace l3k::dev
@@ -213,6 +214,11 @@ struct FastCfg
     // field groups whose LDS reads are issued together in the LDS -> LDS stages (2 * N1 doubles of registers per extra group).
     // (order 4 at three waves per SIMD, 168 registers, was tried again with read_block = 1: still 34 spilled registers.)
     static constexpr int read_block   = NG;
+    // the multi-column variant (all n_rhs columns per element pass) is used where the kernel has registers to spare: with
+    // several elements per wave (orders <= 4: +2 % over column-by-column launches at order 4, 3 columns).  With one element
+    // per wave the variant spills (order 6: 45 registers) and loses 12-17 % against column-by-column launches of the
+    // single-column kernel (tools/bench_multicol.py), which those shapes therefore keep.
+    static constexpr bool multi_column = EW > 1;
 };
 
 // SPLIT: ghost rows live in buffers of their own (a.xg / a.yg, the reference's import / export buffers): every node needs
@@ -222,7 +228,11 @@ struct FastCfg
 // saves the separate dot-product pass over two vectors).
 // AFFINE: every element of the launch is a parallelepiped (its tri-linear map is affine: l3k_mesh_create checks the vertices):
 // one Jacobian per element, inverted once per element instead of once per quadrature point.
-template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false >
+// MULTI: a.n_cols columns per element pass (the reference applies all n_rhs columns in one sweep over the elements,
+// MatrixFreeSystem.hpp:678-688): node ids, vertices, flags and the work ticket are fetched once per element, the stages run
+// once per column (the geometry is recomputed: no registers to keep 343 Jacobians).  A variant of its own, so that the
+// single-column kernel's code and register allocation stay what they are.
+template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -348,9 +358,12 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 ids[k] = en[k * N1 * N1];
         }
     };
+    [[maybe_unused]] int col = 0; // MULTI: the column of this pass
     auto loadX = [&](bool mine, const uint32_t (&ids)[N1], bool flagged) {
         if (!mine)
             return;
+        const double* const ax  = MULTI ? a.x + size_t(col) * a.ldx : a.x;
+        const double* const axg = MULTI && SPLIT ? a.xg + size_t(col) * a.ldxg : a.xg;
         // node-interleaved dofs with the kernel's unknowns = all dofs of a node (the launcher sends every other layout
         // to the generic kernel): 16-byte vector loads, adjacent lanes read adjacent nodes
         // (dofs/NodeToDofMap.hpp:250-264 layout)
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         for (int k = 0; k < N1; ++k)
         {
             const int64_t node = ids[k];
-            const double* p    = !SPLIT || node < n_owned_nodes ? a.x + node * U : a.xg + (node - n_owned_nodes) * U;
+            const double* p    = !SPLIT || node < n_owned_nodes ? ax + node * U : axg + (node - n_owned_nodes) * U;
 #pragma unroll
             for (int hh = 0; hh < U / 2; ++hh)
             {
@@ -411,6 +424,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         const bool w_all = worker & act;
         const bool w_nn = N1 == NQ ? w_all : (w_all & (l < N1 * N1)), w_nq = N1 == NQ ? w_all : (w_all & (l < N1 * NQ)),
                    w_qq = N1 == NQ ? w_all : (w_all & (l < NQ * NQ));
+        int        batch_next = 0;
+        col                   = 0;
+        do // (MULTI: once per column; otherwise a single pass and no loop in the code)
+        {
         // all gather loads of this element are issued back to back (one exposed latency, hidden by the other resident
         // waves); only the next element's node ids are prefetched: holding the next x values in registers across the
         // compute phase made the compiler spill them and wait on every load (profiles/r01 notes in DESIGN.md)
@@ -914,8 +931,13 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         } // if (w_all)
         stageFence(); // (every lane: the scatter below reads what the pencil lanes staged)
         L3K_STAMP(11);
-        const int batch_next = dyn ? ticketBatch(ticket) : batch + stride;
-        loadIds(batch_next, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
+        if (!MULTI || col == (a.n_cols > 1 ? a.n_cols : 1) - 1)
+        {
+            batch_next = dyn ? ticketBatch(ticket) : batch + stride;
+            loadIds(batch_next, ids_nxt, flag_nxt); // next element's node ids: in flight behind the scatter
+        }
+        double* const ay  = MULTI ? a.y + size_t(col) * a.ldy : a.y;
+        double* const ayg = MULTI && SPLIT ? a.yg + size_t(col) * a.ldyg : a.yg;
         // ---- scatter (scatterSumFact, MatrixFreeSystem.hpp:494-537) in SLOT order by all 64 lanes: slots [0, nsh) are the
         // shell nodes in ascending-id order of a typical element -- one double per lane and round, so that an atomic
         // wave-instruction covers runs of contiguous dofs with every 64-byte request full (the memory-side atomic units
@@ -947,7 +969,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 const int64_t node = ids1[r * (SG / U)];
                 const int64_t dof  = node * U + sl_o;
                 const double  val  = sb1[r * SG];
-                double*       dst  = !SPLIT || node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                double*       dst  = !SPLIT || node < n_owned_nodes ? ay + dof : ayg + (dof - a.n_owned_dofs);
                 if constexpr (FLAGGED)
                     if (a.dirichlet[dof] != 0)
                         return;
@@ -967,7 +989,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 const int64_t node = ids2[NSH_ + r * (SG / (U / 2))];
                 const int64_t dof  = node * U + sl_o2;
                 const double2 val  = sb2[NSH_ * (U / 2) + r * SG];
-                double*       dst  = a.y + dof; // (exclusive nodes are owned)
+                double*       dst  = ay + dof; // (exclusive nodes are owned)
                 double2       out  = val;
                 if constexpr (FLAGGED)
                 {
@@ -1028,14 +1050,14 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     {
                         const int64_t node = nid[r];
                         const int64_t dof  = node * U + sl_o;
-                        double*       dst  = !SPLIT || node < n_owned_nodes ? a.y + dof : a.yg + (dof - a.n_owned_dofs);
+                        double*       dst  = !SPLIT || node < n_owned_nodes ? ay + dof : ayg + (dof - a.n_owned_dofs);
                         unsafeAtomicAdd(dst, val[r]);
                     }
 #pragma unroll
                 for (int r = 0; r < RX; ++r)
                     if (r + 1 < RX || in2)
                     {
-                        double* dst = a.y + int64_t(nid2[r]) * U + sl_o2; // (exclusive nodes are owned)
+                        double* dst = ay + int64_t(nid2[r]) * U + sl_o2; // (exclusive nodes are owned)
                         double2 out = val2[r];
                         if (a.beta != 0.)
                         {
@@ -1071,6 +1093,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         }
         stageFence(); // the buffers are rewritten by the next batch
         L3K_STAMP(12);
+        } while (MULTI && ++col < a.n_cols);
 #pragma unroll
         for (int k = 0; k < N1; ++k)
             ids_cur[k] = ids_nxt[k];
@@ -1090,12 +1113,17 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #endif
 }
 
-template < typename K, int P, int NQ >
-int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+template < typename K, int P, int NQ, bool MULTI >
+int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
 {
     using Cfg = FastCfg< K, P, NQ >;
     if (a.elem_count <= 0)
         return 0;
+    if (MULTI && a.n_cols < 1)
+    {
+        setError("multi-column element launch without a column count");
+        return -1;
+    }
     // Small launches are latency-bound: one element takes ~23 us through a single wave here, ~15 us through the 6-wave
     // workgroup of the generic kernel; below ~3 elements per CU the generic kernel wins (profiles/r01_kbench_small_meshes.log:
     // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements).  L3K_GENERIC_BELOW overrides.
@@ -1103,16 +1131,41 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
     const long        generic_below = gb_env ? std::atol(gb_env) : 1500L;
     constexpr bool generic_fits = applyLdsBytes< K, P, NQ, 1 >() <= lds_limit_bytes;
     if (!a.dense || (generic_fits && a.elem_count < generic_below)) // (non-dense dof layouts: generic kernel only)
-        return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);
+    {
+        if constexpr (!MULTI)
+            return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);
+        else
+        {
+            for (int c = 0; c < a.n_cols; ++c) // column by column through the generic single-column kernel
+            {
+                ElemArgs ac = a;
+                ac.n_cols   = 1;
+                ac.x        = a.x + a.ldx * c;
+                ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
+                ac.y        = a.y + a.ldy * c;
+                ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
+                if (int rc = launchSumfactApply< K, P, NQ, 1, false >(ac, kparam_blob, stream))
+                    return rc;
+            }
+            return 0;
+        }
+    }
     K kern{};
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
-    const bool  split    = !((a.xg == nullptr || a.xg == a.x + a.n_owned_dofs) && (a.yg == nullptr || a.yg == a.y + a.n_owned_dofs));
+    // (ghost rows directly behind the owned rows of every column: one base pointer per column serves both)
+    const bool  contiguous = (a.xg == nullptr || (a.xg == a.x + a.n_owned_dofs && (!MULTI || a.ldxg == a.ldx))) &&
+                            (a.yg == nullptr || (a.yg == a.y + a.n_owned_dofs && (!MULTI || a.ldyg == a.ldy)));
+    const bool  split    = !contiguous;
     // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
-    const bool  affine   = a.all_affine && !split && !a.energy && std::getenv("L3K_NO_AFFINE") == nullptr;
-    auto        kernel   = affine ? sumfactFastKernel< K, P, NQ, false, false, true >
-                           : a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
-                                      : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
+    const bool  affine   = !MULTI && a.all_affine && !split && !a.energy && std::getenv("L3K_NO_AFFINE") == nullptr;
+    decltype(&sumfactFastKernel< K, P, NQ, false, false >) kernel;
+    if constexpr (MULTI) // (no fused energy, no affine variant: plain applies of several columns)
+        kernel = split ? sumfactFastKernel< K, P, NQ, true, false, false, true > : sumfactFastKernel< K, P, NQ, false, false, false, true >;
+    else
+        kernel = affine ? sumfactFastKernel< K, P, NQ, false, false, true >
+                 : a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
+                            : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
     // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
     // attribute of the four variants is set once on each device, under a lock
     struct PerDevice
@@ -1135,11 +1188,16 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         PerDevice&                    pd = per_device[dev];
         if (!pd.ready)
         {
-            const void* const variants[5] = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
-                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
-                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
-                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >),
-                                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, true >)};
+            std::vector< const void* > variants;
+            if constexpr (MULTI)
+                variants = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false, false, true >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, false, true >)};
+            else
+                variants = {reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, true >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, true >)};
             bool ok = true;
             for (const void* f : variants)
                 ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;
@@ -1199,6 +1257,20 @@ int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t st
         return -3;
     }
     return 0;
+}
+template < typename K, int P, int NQ >
+int launchSumfactFast(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    return launchSumfactFastImpl< K, P, NQ, false >(a, kparam_blob, stream);
+}
+// a.n_cols columns (x, y: column c at + c * ld) in one pass over the elements
+template < typename K, int P, int NQ >
+int launchSumfactFastCols(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    static_assert(FastCfg< K, P, NQ >::multi_column);
+    if (a.n_cols <= 1)
+        return launchSumfactFastImpl< K, P, NQ, false >(a, kparam_blob, stream);
+    return launchSumfactFastImpl< K, P, NQ, true >(a, kparam_blob, stream);
 }
 } // namespace l3k::dev
 #endif
