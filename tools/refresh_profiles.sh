@@ -1,5 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the round's judged measurements.  Outputs under gpurun_out/refresh/.
+# After a change of the kernel sources: run this, then python tools/collect_profiles.py rNN here (writes the traffic profile
+# with the new source hash), then bench.py alone once more into gpurun_out/refresh/bench.json and collect again: the bench line
+# of the first run was printed against the previous traffic profile and says so ("stale").
 set -o pipefail
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/refresh
