@@ -1,6 +1,6 @@
 """Randomised parity sweep of the matrix-free apply against the CPU oracle: random mesh extents (1..8 elements per edge,
 non-cubic), orders 1..8, 1..3 columns, random alpha / beta, random Dirichlet sides and unknowns, perturbed or uniform
-geometry, fast (single-wave) and generic kernel routes (L3K_GENERIC_BELOW drawn per case), deterministic mode on a
+geometry, diag + lifted rhs on a third of the single-column cases, fast (single-wave) and generic kernel routes (L3K_GENERIC_BELOW drawn per case), deterministic mode on a
 fraction of the cases.  Prints the worst relative error; exits non-zero on a case above 1e-11.
     python tools/fuzz_apply.py [--seconds 120] [--seed 0]"""
 import argparse, os, sys, time
@@ -49,6 +49,12 @@ while time.time() < t_end:
     err = rel_err(Y.cpu().numpy().T, y_ref)
     case = dict(p=p, ne=ne, ncols=ncols, perturb=perturb, alpha=alpha, beta=beta, sides=sides, unknowns=unknowns, det=det,
                 generic_below=os.environ["L3K_GENERIC_BELOW"])
+    if ncols == 1 and rng.random() < 0.3:  # diag + lifted rhs of the same system (MatrixFreeSystem::computeDiagAndRhs)
+        g = rng.uniform(-1, 1, (1, part.n_local_nodes * U)) * mask[None, :]
+        diag, rhs = mf.diag_rhs(dev(g))
+        torch.cuda.synchronize()
+        d_ref, r_ref = O.mf_diag_rhs(oracle_mesh(part, p + 1, U, np.arange(U), mask), kid, 1, np.asfortranarray(g.T), kparams=[0.7, 1.0])
+        err = max(err, rel_err(diag.cpu().numpy(), d_ref), rel_err(rhs.cpu().numpy().T, r_ref))
     n += 1
     if err > worst[0]:
         worst = (err, case)
