@@ -210,3 +210,36 @@ def test_save_load_round_trip_of_mesh_and_results(tmp_path):
         gids = part.node_grid_id  # owned and ghost nodes by the file's global ids
         for k in range(2):
             assert np.allclose(native_io.load(res_path, k, node_ids=gids), f(coords)[k], atol=1e-14)
+
+
+def _save_worker(rank, world, port, path, order):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        part = system.CubePartition((4, 2, 2), order, parts=(world, 1, 1), rank=rank, perturb=0.1)
+        sizes = mesh_file.save_partition(path, part, comment="saved by two ranks")  # the sizes travel through all_gather_object
+        assert len(sizes) == world
+        dist.barrier()
+        again = mesh_file.FilePartition(path, rank, order)
+        assert again.n_elems == part.n_elems and again.n_owned_nodes == part.n_owned_nodes
+        assert np.array_equal(again.ghost_global_id, part.ghost_global_id)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_save_their_parts_through_torch_distributed(tmp_path):
+    """save(comm, mesh, path, comment) of the reference: every rank serialises its part, the sizes are gathered, rank 0 writes
+    the header (post/NativeIO.hpp:75-108) -- here with the gloo backend, two processes."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "two.mesh")
+    mp.spawn(_save_worker, args=(2, port, path, 2), nprocs=2, join=True)
+    assert len(mesh_file.info(path)) == 2
+    comment, parts = ONP.mesh_file_parse(open(path, "rb").read(), 2)
+    assert comment == "saved by two ranks" and len(parts) == 2
+    whole = system.CubePartition((4, 2, 2), 2, perturb=0.1)
+    assert sum(p[2] for p in parts) == whole.n_global_nodes  # owned node counts add up to the mesh
