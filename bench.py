@@ -33,8 +33,9 @@ PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # active lanes per element): order 6: 4 460 lane-flops x 49 lanes
 FP64_FLOP_PER_ELEM = {6: 4460 * 49}
 # executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u): per workgroup 7
-# iterations (one bx' each) of stage 1: 7 pairs x 49 x 112, stage 2: 343 rows x 441, stage 3: 343 rows x 49 columns x 28 FMAs, + G
-SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (7 * (7 * 49 * 112 + 343 * 441 + 343 * 49 * 28) + 343 * 16 * 7)
+# iterations (one bx' each) of stage 1: 7 pairs x 49 x 112, stage 2: 343 rows x 441, stage 3 (factorised: 4 nq n + 2 nq n^2 per
+# row): 343 rows x 882 FMAs, + G
+SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (7 * (7 * 49 * 112 + 343 * 441 + 343 * 882) + 343 * 16 * 7)
 
 
 def algorithmic_bytes_per_dof(p, U, F=0):
@@ -257,7 +258,7 @@ def main():
         if world == 1 and op is None and p == 6:
             # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly, order 6, streaming mode
             # (checksums instead of 15 MB per matrix); outside the timed region.  Default algorithm: sum-factorised assembly
-            # (device/assemble.hpp: ~98 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
+            # (device/assemble.hpp: ~70 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
             # the FP64 matrix cores (4 523 MFLOP per element using symmetry), the formulation the reference computes
             batch, reps = 512, 3
             apart = system.CubePartition(8, p, perturb=0.1)
@@ -288,8 +289,9 @@ def main():
                                         "algorithm": "sum-factorised assembly on index pairs (O(n^7) per pair of unknowns), FP64 vector pipe",
                                         "roofline": {"bound": "mfma", "achieved": rate * sf_flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                                      "frac": rate * sf_flops / 1e12 / 78.6,
-                                                     "flops": "executed: 93.2 MFLOP per element; FP64 matrix and vector pipes are one pipe "
-                                                              "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)",
+                                                     "flops": "executed: %.1f MFLOP per element; FP64 matrix and vector pipes are one pipe "
+                                                              "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)"
+                                                              % (sf_flops / 1e6),
                                                      "dense_equivalent_tflops": rate * dense_flops / 1e12},
                                         "dense_mfma_kernel": {"value": rate_dense, "unit": "element matrices/s",
                                                               "roofline": {"bound": "mfma", "achieved": rate_dense * dense_flops / 1e12,

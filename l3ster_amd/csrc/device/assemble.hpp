@@ -320,22 +320,27 @@ struct SfAsmCfg
     // G | P | A
     static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * AROW);
     static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
-    static constexpr size_t pz_doubles = size_t(N2) * K3; // the z product table in global memory: [column (bz, bz')][(tz, qz)]
 };
 
 // Stage 1 is cooperative (A[bx][group][qz][qy] for the iteration's bx', through LDS); stages 2 and 3 are fused per row:
 // the thread of row (bx, by, by') forms its 4 nq values B[tz][qz] in registers from its own rows of the y product tables (28
-// doubles loaded once per workgroup) and the A arrays (LDS reads shared by the 49 threads of a bx), then runs over the n^2
-// columns (bz, bz') with the z product table read by SCALAR loads (wave-uniform: 28 SGPR-pair operands per column, no LDS
-// operand traffic in the stage that holds 72 % of the flops).
+// doubles re-read from LDS per iteration) and the A arrays (LDS reads shared by the 49 threads of a bx), then forms the n^2
+// entries (bz, bz') of its row in two steps (the z product table is a product of the two 1-D tables: stage 3 below), with
+// the 1-D tables read by SCALAR loads (wave-uniform SGPR-pair operands: no LDS operand traffic in that stage).
+__device__ __forceinline__ int opaqueOffset(int x)
+{
+    int y;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
 template < typename K, int P, int NQ >
 __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
-                                                                                       const double* __restrict__ pz_table, int64_t elem0)
+                                                                                       int64_t elem0)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = SfAsmCfg< P, NQ >;
-    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, ROWS = C::ROWS, K3 = C::K3, AROW = C::AROW;
+    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, ROWS = C::ROWS, AROW = C::AROW;
     constexpr int         NT = C::threads, ND = N1 * N2 * U;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
@@ -397,17 +402,9 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     // this thread's row (bx = pp, by, by') and its rows of the y product tables
     const bool has_row = tid < ROWS;
     const int  row = has_row ? tid : 0, pp = row / N2, bb = row - pp * N2, by = bb % N1, byp = bb / N1;
-    double     py[4][NQ];
-#pragma unroll
-    for (int ty = 0; ty < 4; ++ty)
-#pragma unroll
-        for (int qy = 0; qy < NQ; ++qy)
-            py[ty][qy] = Pt[(ty * N2 + bb) * NQ + qy];
 
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
-    const __attribute__((address_space(4))) double* const pz =
-        reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(pz_table));
 
     for (int bxp = 0; bxp < N1; ++bxp)
     {
@@ -445,6 +442,17 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
         if (has_row)
         {
             // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]
+            // (this row's 4 nq entries of the y product table are re-read from LDS in every iteration: held across stage 3
+            // they cost 2 * 4 nq registers where stage 3 has none to spare)
+            double py[4][NQ];
+            {
+                const double* pt = Pt + opaqueOffset(bb * NQ);
+#pragma unroll
+                for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+                    for (int qy = 0; qy < NQ; ++qy)
+                        py[ty][qy] = pt[ty * N2 * NQ + qy];
+            }
             double B[4][NQ];
 #pragma unroll
             for (int tz = 0; tz < 4; ++tz)
@@ -469,45 +477,71 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 }
             // ---- stage 3: M[row][(bz,bz')] = sum_{tz,qz} B[tz][qz] Pz[(bz,bz')][(tz,qz)], the table through scalar loads
             const int rowb = pp + N1 * by, rowbp = bxp + N1 * byp;
-            // (a software pipeline over half columns -- the next scalar loads issued behind the wait for the current ones -- was
-            // tried: 147 k instead of 165 k matrices/s; the three resident waves per SIMD hide the scalar-load latency better)
-            // Output bookkeeping hoisted out of the column loop: b - b' = (rowb - rowbp) + N2 (bz - bz') has the sign of bz - bz'
+            // Output bookkeeping hoisted out of the entry loops: b - b' = (rowb - rowbp) + N2 (bz - bz') has the sign of bz - bz'
             // unless they are equal, and the checksum weight 1 + (31 gi + 17 gj) mod 7 = 1 + 3 (gi + gj) mod 7 does not depend
             // on (bz, bz') when N2 U is a multiple of 7 (order 6: 196): three partial sums per row instead of ~15 integer
-            // instructions per entry.  The columns are fully unrolled: (bz, bz') are compile-time and the table's scalar loads
-            // are issued far ahead of their use (162 k -> 193 k matrices/s at order 6; 256 registers, one workgroup per CU.
-            // Capped at 168 registers for two workgroups per CU: 167 k, 81 spilled registers; unrolled by bz only: 154-160 k).
+            // instructions per entry.  All loops are unrolled: (bz, bz') are compile-time and the scalar loads are issued ahead
+            // of their use.  (History at order 6: per-entry bookkeeping + rolled columns 162 k matrices/s -> unrolled, hoisted
+            // 193 k -> factorised 218 k.)
             constexpr bool wgt_const = (N2 * U) % 7 == 0;
             const int      dlt       = rowb - rowbp; // sign of b - b' on the bz == bz' columns
             double         s_lo = 0., s_eq = 0., s_up = 0.; // sums over the columns with bz > bz', bz == bz', bz < bz'
+            // Stage 3 is sum-factorised once more: the z product table is itself a product, Pz[(bz,bz')][(s + 2 s', qz)] =
+            // T_s[bz][qz] T_s'[bz'][qz] (T_0 = I, T_1 = D), so M[bz][bz'] = sum_{s',qz} W[bz][s'][qz] T_s'[bz'][qz] with
+            // W[bz][s'][qz] = sum_s B[s + 2 s'][qz] T_s[bz][qz]: 4 nq n + 2 nq n^2 = 882 FMAs per row instead of 4 nq n^2 = 1 372,
+            // and every scalar operand of the second step (the 1-D tables through scalar loads) serves a block of ZB values of bz
+            // instead of one entry -- the first form waited for its scalar loads (56 scalar registers per column)
+            constexpr int ZB = 2; // values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills)
+            const __attribute__((address_space(4))) double* const tIz =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
+            const __attribute__((address_space(4))) double* const tDz =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offD()));
 #pragma unroll
-            for (int c = 0; c < N2; ++c)
+            for (int b0 = 0; b0 < N1; b0 += ZB)
             {
-                const __attribute__((address_space(4))) double* pc = pz + c * K3;
-                double                                          m  = 0.;
+                double W[ZB][2][NQ];
 #pragma unroll
-                for (int tz = 0; tz < 4; ++tz)
+                for (int bi = 0; bi < ZB; ++bi)
+                    if (b0 + bi < N1)
+                    {
 #pragma unroll
-                    for (int qz = 0; qz < NQ; ++qz)
-                        m += B[tz][qz] * pc[tz * NQ + qz];
-                const int  bz = c % N1, bzp = c / N1;
-                const int  b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
-                const bool skip = u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
-                const int  gi = b * U + u, gj = bp * U + up;
-                if (Kel && !skip)
-                {
-                    Kel[int64_t(gi) * ND + gj] = m;
-                    if (gi != gj)
-                        Kel[int64_t(gj) * ND + gi] = m;
-                }
-                if constexpr (wgt_const)
-                {
-                    s_lo += bz > bzp ? m : 0.;
-                    s_eq += bz == bzp ? m : 0.;
-                    s_up += bz < bzp ? m : 0.;
-                }
-                else if (!skip)
-                    csum += (gi != gj ? 2. : 1.) * double(1 + (gi * 31 + gj * 17) % 7) * m;
+                        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                            for (int qz = 0; qz < NQ; ++qz)
+                                W[bi][sp][qz] = B[2 * sp][qz] * tIz[(b0 + bi) * NQ + qz] + B[2 * sp + 1][qz] * tDz[(b0 + bi) * NQ + qz];
+                    }
+#pragma unroll
+                for (int bzp = 0; bzp < N1; ++bzp)
+#pragma unroll
+                    for (int bi = 0; bi < ZB; ++bi)
+                        if (b0 + bi < N1)
+                        {
+                            const int bz = b0 + bi;
+                            double    m  = 0.;
+#pragma unroll
+                            for (int qz = 0; qz < NQ; ++qz)
+                                m += W[bi][0][qz] * tIz[bzp * NQ + qz];
+#pragma unroll
+                            for (int qz = 0; qz < NQ; ++qz)
+                                m += W[bi][1][qz] * tDz[bzp * NQ + qz];
+                            const int  b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
+                            const bool skip = u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
+                            const int  gi = b * U + u, gj = bp * U + up;
+                            if (Kel && !skip)
+                            {
+                                Kel[int64_t(gi) * ND + gj] = m;
+                                if (gi != gj)
+                                    Kel[int64_t(gj) * ND + gi] = m;
+                            }
+                            if constexpr (wgt_const)
+                            {
+                                s_lo += bz > bzp ? m : 0.;
+                                s_eq += bz == bzp ? m : 0.;
+                                s_up += bz < bzp ? m : 0.;
+                            }
+                            else if (!skip)
+                                csum += (gi != gj ? 2. : 1.) * double(1 + (gi * 31 + gj * 17) % 7) * m;
+                        }
             }
             if constexpr (wgt_const)
             {
@@ -573,9 +607,9 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         if (!dense)
         {
             auto ks = assembleSumfactKernel< K, P, NQ >;
-            // the z product table Pz[(bz,bz')][(tz,qz)] = T_s[bz][qz] T_s'[bz'][qz] depends on (P, NQ) only: built once per device
-            static double*    pz_dev[64] = {};
-            static std::mutex pz_mutex;
+            // (the dynamic-LDS attribute is set once per device, under a lock)
+            static bool       attr_set[64] = {};
+            static std::mutex attr_mutex;
             int               dev = 0;
             (void)hipGetDevice(&dev);
             if (dev < 0 || dev >= 64)
@@ -584,33 +618,19 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                 return -3;
             }
             {
-                std::lock_guard< std::mutex > lock{pz_mutex};
-                if (!pz_dev[dev])
+                std::lock_guard< std::mutex > lock{attr_mutex};
+                if (!attr_set[dev])
                 {
                     if (hipFuncSetAttribute(reinterpret_cast< const void* >(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) != hipSuccess)
                     {
                         setError("hipFuncSetAttribute failed for the sum-factorised assembly kernel");
                         return -3;
                     }
-                    constexpr TableLayout TL{P + 1, NQ};
-                    std::vector< double > pz(S::pz_doubles);
-                    const double *        tI = a.tables_host + TL.offI(), *tD = a.tables_host + TL.offD();
-                    for (int c = 0; c < S::N2; ++c)
-                        for (int tz = 0; tz < 4; ++tz)
-                            for (int qz = 0; qz < NQ; ++qz)
-                                pz[size_t(c) * S::K3 + tz * NQ + qz] = ((tz & 1) ? tD : tI)[(c % S::N1) * NQ + qz] * ((tz & 2) ? tD : tI)[(c / S::N1) * NQ + qz];
-                    double* d = nullptr;
-                    if (hipMalloc(reinterpret_cast< void** >(&d), pz.size() * sizeof(double)) != hipSuccess ||
-                        hipMemcpy(d, pz.data(), pz.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-                    {
-                        setError("allocation of the assembly product table failed");
-                        return -3;
-                    }
-                    pz_dev[dev] = d;
+                    attr_set[dev] = true;
                 }
             }
             hipLaunchKernelGGL(ks, dim3(U * (U + 1) / 2, static_cast< unsigned >(a.elem_count)), dim3(S::threads), S::lds, stream, a, cbuf,
-                               pz_dev[dev], int64_t(a.elem_begin_out));
+                               int64_t(a.elem_begin_out));
         }
     if (dense)
         hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,
