@@ -96,19 +96,21 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel
         in.point = SpaceTimePoint{Point3{{xyz[0], xyz[1], xyz[2]}}, a.time};
         typename Iface::Result res{};
         kern(in, res);
-        double* c = cbuf + (el * NQP + q) * CS;
+        // records of one element as [entry][q] (structure of arrays): neighbouring threads = neighbouring quadrature points
+        // write, and the assembly kernels read, neighbouring addresses
+        double* c = cbuf + el * NQP * CS + q;
 #pragma unroll
         for (int e_ = 0; e_ < E; ++e_)
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
-                c[(e_ * U + u) * 4 + 0] = res.operators[0](e_, u);
+                c[((e_ * U + u) * 4 + 0) * NQP] = res.operators[0](e_, u);
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    c[(e_ * U + u) * 4 + 1 + d] = res.operators[1](e_, u) * Ji[d][0] + res.operators[2](e_, u) * Ji[d][1] +
-                                                  res.operators[3](e_, u) * Ji[d][2];
+                    c[((e_ * U + u) * 4 + 1 + d) * NQP] = res.operators[1](e_, u) * Ji[d][0] + res.operators[2](e_, u) * Ji[d][1] +
+                                                          res.operators[3](e_, u) * Ji[d][2];
             }
-        c[CS - 1] = qw[qx] * qw[qy] * qw[qz] * det;
+        c[(CS - 1) * NQP] = qw[qx] * qw[qy] * qw[qz] * det;
         if (!(det > 0.)) // reference: "Encountered degenerate element ( |J| <= 0 )" (AssembleLocalSystem.hpp:249)
             a.workspace[int64_t(a.elem_count) * NQP * CS] = 1.;
     }
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256, L3K_GEMM_MIN_BLOCKS) void assembleGemmKernel(c
         // ---- stage the chunk's coefficient records (contiguous in the workspace) in LDS
         for (int i = tid; i < QC * CS; i += 256)
         {
-            const int qi = i / CS, r = i - qi * CS;
-            cs[qi * CSP + r] = q0 + qi < NQP ? cel[int64_t(q0) * CS + i] : 0.;
+            const int r = i / QC, qi = i - r * QC; // (the workspace holds [entry][q]: consecutive threads read consecutive q)
+            cs[qi * CSP + r] = q0 + qi < NQP ? cel[int64_t(r) * NQP + q0 + qi] : 0.;
         }
         __syncthreads();
         // ---- generate the two Z chunks: the basis products of (column, q) once, then 4 FMAs per equation
@@ -374,16 +376,16 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     const double* cel = cbuf + el * NQP * CS;
     for (int q = tid; q < NQP; q += NT)
     {
-        const double* cq = cel + int64_t(q) * CS;
-        const double  w  = cq[CS - 1];
+        const double* cq = cel + q; // [entry][q]
+        const double  w  = cq[(CS - 1) * NQP];
         double        cu[E][4], cp[E][4];
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
             {
-                cu[e][k] = cq[(e * U + u) * 4 + k];
-                cp[e][k] = cq[(e * U + up) * 4 + k];
+                cu[e][k] = cq[((e * U + u) * 4 + k) * NQP];
+                cp[e][k] = cq[((e * U + up) * 4 + k) * NQP];
             }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
