@@ -411,34 +411,40 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     for (int bxp = 0; bxp < N1; ++bxp)
     {
         const int pair0 = bxp * N1; // pairs (bx, bx') = bx + N1 bx', bx = 0 .. N1-1
-        // ---- stage 1: A[bx][g][qz][qy]; the group is the slowest index of the work list, so a wave runs one group's
-        // compile-time term list
-        for (int i = tid; i < 9 * PAIRS * NQ * NQ; i += NT)
+        // ---- stage 1: A[bx][g][qz][qy] for the pairs (bx, bx' = bxp): one thread per (bx, qy, qz) forms all nine groups from its
+        // 16 x nq entries of G and the 4 x nq entries of the x product table of its pair -- one straight-line body of 16
+        // independent 7-term sums with compile-time term lists (the earlier form dealt (group, bx, qy, qz) items to the
+        // threads: a switch per item, the product-table row re-read per term, three to five LDS reads in flight)
+        for (int it = tid; it < PAIRS * NQ * NQ; it += NT)
         {
-            const int g = i / (PAIRS * NQ * NQ), r = i - g * (PAIRS * NQ * NQ), bx = r / (NQ * NQ), qyz = r - bx * (NQ * NQ);
+            const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ);
             const int pair = pair0 + bx;
-            double    acc  = 0.;
-            const auto term = [&](int k, int kp) {
-                const int     tx = (k == 1) + 2 * (kp == 1);
-                const double* px = Pt + (tx * N2 + pair) * NQ;
-                const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
+            double    pxv[4][NQ];
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx)
 #pragma unroll
                 for (int qx = 0; qx < NQ; ++qx)
-                    acc += px[qx] * gq[qx];
-            };
-            switch (g)
-            {
-            case 0: term(0, 0), term(0, 1), term(1, 0), term(1, 1); break; // (ty, tz) = (II, II)
-            case 1: term(2, 0), term(2, 1); break;                         // (DI, II)
-            case 2: term(0, 2), term(1, 2); break;                         // (ID, II)
-            case 3: term(2, 2); break;                                     // (DD, II)
-            case 4: term(3, 0), term(3, 1); break;                         // (II, DI)
-            case 5: term(0, 3), term(1, 3); break;                         // (II, ID)
-            case 6: term(3, 3); break;                                     // (II, DD)
-            case 7: term(2, 3); break;                                     // (DI, ID)
-            default: term(3, 2); break;                                    // (ID, DI)
-            }
-            A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = acc;
+                    pxv[tx][qx] = Pt[(tx * N2 + pair) * NQ + qx];
+            double accg[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp)
+                {
+                    // group (ty, tz) of the term (k, k'): type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1)
+                    constexpr int gtab[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}}; // [ty][tz]
+                    const int     ty = (k == 2) + 2 * (kp == 2), tz = (k == 3) + 2 * (kp == 3), tx = (k == 1) + 2 * (kp == 1);
+                    const int     g  = gtab[ty][tz];
+                    const double* gq = G + (k * 4 + kp) * NQP + qyz * NQ;
+                    double        t  = 0.;
+#pragma unroll
+                    for (int qx = 0; qx < NQ; ++qx)
+                        t += pxv[tx][qx] * gq[qx];
+                    accg[g] += t;
+                }
+#pragma unroll
+            for (int g = 0; g < 9; ++g)
+                A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = accg[g];
         }
         __syncthreads();
         if (has_row)
