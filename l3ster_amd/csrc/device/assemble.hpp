@@ -499,6 +499,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
             // W[bz][s'][qz] = sum_s B[s + 2 s'][qz] T_s[bz][qz]: 4 nq n + 2 nq n^2 = 882 FMAs per row instead of 4 nq n^2 = 1 372,
             // and every scalar operand of the second step (the 1-D tables through scalar loads) serves a block of ZB values of bz
             // instead of one entry -- the first form waited for its scalar loads (56 scalar registers per column)
+            const bool    diag_block = u == up;
             constexpr int ZB = 2; // values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills)
             const __attribute__((address_space(4))) double* const tIz =
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
@@ -522,7 +523,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 for (int bzp = 0; bzp < N1; ++bzp)
 #pragma unroll
                     for (int bi = 0; bi < ZB; ++bi)
-                        if (b0 + bi < N1)
+                        if (b0 + bi < N1 && !(diag_block && bzp > b0 + bi)) // (diagonal blocks: b_z' > b_z is the mirror image)
                         {
                             const int bz = b0 + bi;
                             double    m  = 0.;
