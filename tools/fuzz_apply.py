@@ -21,6 +21,7 @@ rng = np.random.default_rng(a.seed)
 torch.cuda.set_device(0)
 dev = lambda v: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float64, device="cuda")
 t_end, n, worst = time.time() + a.seconds, 0, (0.0, None)
+t_progress = time.time() + 60.0
 U, kid = 4, system.KERNEL_DIFFUSION3D
 while time.time() < t_end:
     p = int(rng.integers(1, 9))
@@ -56,6 +57,9 @@ while time.time() < t_end:
         d_ref, r_ref = O.mf_diag_rhs(oracle_mesh(part, p + 1, U, np.arange(U), mask), kid, 1, np.asfortranarray(g.T), kparams=[0.7, 1.0])
         err = max(err, rel_err(diag.cpu().numpy(), d_ref), rel_err(rhs.cpu().numpy().T, r_ref))
     n += 1
+    if time.time() > t_progress:  # (a long run must keep writing: the GPU box takes 7 silent minutes for a hang)
+        print(f"... {n} cases so far, worst {worst[0]:.3e}", flush=True)
+        t_progress = time.time() + 60.0
     if err > worst[0]:
         worst = (err, case)
     if not err < 1e-11:

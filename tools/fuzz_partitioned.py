@@ -39,6 +39,7 @@ torch.cuda.set_device(0)
 dev = lambda v: torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float64, device="cuda")
 U, kid = 4, system.KERNEL_DIFFUSION3D
 t_end, n, worst = time.time() + a.seconds, 0, (0.0, None)
+t_progress = time.time() + 60.0
 while time.time() < t_end:
     while True:
         parts = tuple(int(v) for v in rng.integers(1, 4, 3))
@@ -94,6 +95,9 @@ while time.time() < t_end:
         seen += len(rows)
     err = (num / max(den, 1e-300)) ** 0.5
     n += 1
+    if time.time() > t_progress:  # (a long run must keep writing: the GPU box takes 7 silent minutes for a hang)
+        print(f"... {n} cases so far, worst {worst[0]:.3e}", flush=True)
+        t_progress = time.time() + 60.0
     if err > worst[0]:
         worst = (err, case)
     if seen != whole.n_local_nodes or not err < 1e-11:
