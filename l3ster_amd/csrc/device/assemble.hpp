@@ -329,6 +329,57 @@ struct SfAsmCfg
 // doubles re-read from LDS per iteration) and the A arrays (LDS reads shared by the 49 threads of a bx), then forms the n^2
 // entries (bz, bz') of its row in two steps (the z product table is a product of the two 1-D tables: stage 3 below), with
 // the 1-D tables read by SCALAR loads (wave-uniform SGPR-pair operands: no LDS operand traffic in that stage).
+// out[q] (+)= sum_b in[b] W[b][q] from the even-odd tables We | Wo of W (host/tables.cpp:evenOddTables; the same scheme as
+// sweepEO of device/sumfact_fast.hpp), the tables read through the constant address space: scalar loads, SGPR operands
+template < int NIN, int NOUT, bool ANTI, bool ACC >
+__device__ __forceinline__ void sweepEOScalar(const double (&in)[NIN], double (&out)[NOUT],
+                                              const __attribute__((address_space(4))) double* eo)
+{
+    constexpr int HI = NIN / 2, HO = NOUT / 2, RI = (NIN + 1) / 2, RO = (NOUT + 1) / 2;
+    const __attribute__((address_space(4))) double* const We = eo;
+    const __attribute__((address_space(4))) double* const Wo = eo + RI * RO;
+    double                                                e[RI], o[HI > 0 ? HI : 1];
+#pragma unroll
+    for (int r = 0; r < HI; ++r)
+    {
+        e[r] = in[r] + in[NIN - 1 - r];
+        o[r] = in[r] - in[NIN - 1 - r];
+    }
+    if constexpr (NIN % 2)
+        e[HI] = in[HI];
+#pragma unroll
+    for (int q = 0; q < HO; ++q)
+    {
+        double A = 0.;
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+            A += e[r] * We[r * RO + q];
+        double lo = A;
+#pragma unroll
+        for (int r = 0; r < HI; ++r)
+            lo += o[r] * Wo[r * RO + q];
+        const double hi = ANTI ? lo - 2. * A : 2. * A - lo;
+        out[q]            = ACC ? out[q] + lo : lo;
+        out[NOUT - 1 - q] = ACC ? out[NOUT - 1 - q] + hi : hi;
+    }
+    if constexpr (NOUT % 2)
+    {
+        double m = 0.;
+        if constexpr (ANTI)
+        {
+#pragma unroll
+            for (int r = 0; r < HI; ++r)
+                m += o[r] * Wo[r * RO + HO];
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+                m += e[r] * We[r * RO + HO];
+        }
+        out[HO] = ACC ? out[HO] + m : m;
+    }
+}
 __device__ __forceinline__ int opaqueOffset(int x)
 {
     int y;
@@ -505,6 +556,10 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
             const __attribute__((address_space(4))) double* const tDz =
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offD()));
+            const __attribute__((address_space(4))) double* const eoItz =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offEoIt()));
+            const __attribute__((address_space(4))) double* const eoDtz =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offEoDt()));
 #pragma unroll
             for (int b0 = 0; b0 < N1; b0 += ZB)
             {
@@ -519,20 +574,24 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                             for (int qz = 0; qz < NQ; ++qz)
                                 W[bi][sp][qz] = B[2 * sp][qz] * tIz[(b0 + bi) * NQ + qz] + B[2 * sp + 1][qz] * tDz[(b0 + bi) * NQ + qz];
                     }
+                // second step with the even-odd decomposition of the two 1-D tables (I^T symmetric, D^T antisymmetric): 2 x 34
+                // instead of 2 nq n = 98 instructions per b_z, half as many scalar operands
+                double Mz[ZB][N1];
+#pragma unroll
+                for (int bi = 0; bi < ZB; ++bi)
+                    if (b0 + bi < N1)
+                    {
+                        sweepEOScalar< NQ, N1, false, false >(W[bi][0], Mz[bi], eoItz);
+                        sweepEOScalar< NQ, N1, true, true >(W[bi][1], Mz[bi], eoDtz);
+                    }
 #pragma unroll
                 for (int bzp = 0; bzp < N1; ++bzp)
 #pragma unroll
                     for (int bi = 0; bi < ZB; ++bi)
                         if (b0 + bi < N1 && !(diag_block && bzp > b0 + bi)) // (diagonal blocks: b_z' > b_z is the mirror image)
                         {
-                            const int bz = b0 + bi;
-                            double    m  = 0.;
-#pragma unroll
-                            for (int qz = 0; qz < NQ; ++qz)
-                                m += W[bi][0][qz] * tIz[bzp * NQ + qz];
-#pragma unroll
-                            for (int qz = 0; qz < NQ; ++qz)
-                                m += W[bi][1][qz] * tDz[bzp * NQ + qz];
+                            const int    bz = b0 + bi;
+                            const double m  = Mz[bi][bzp];
                             const int  b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
                             const bool skip = u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
                             const int  gi = b * U + u, gj = bp * U + up;

@@ -46,7 +46,8 @@ struct TableLayout
     constexpr int offDD() const { return offID() + n * nq; }
     constexpr int offE() const { return offDD() + n * nq; } // phi_k'(-1) [n] | phi_k'(+1) [n] (boundary kernels)
     constexpr int offDG() const { return offE() + 2 * n; }  // phi_b'(gll_q), [b][q], n x n (values at the nodes)
-    constexpr int size() const { return offDG() + n * n; }
+    constexpr int offEoDt() const { return offDG() + n * n; } // even-odd tables of D^T (nq -> n, antisymmetric): We | Wo, each hq x hn
+    constexpr int size() const { return offEoDt() + 2 * hq() * hn(); }
 };
 
 // Everything an element kernel needs; passed by value as the kernel argument (scalar loads).

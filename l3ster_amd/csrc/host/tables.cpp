@@ -225,6 +225,12 @@ std::vector< double > deviceTableBlock(int p, int nq)
             dg[size_t(b) * n + q] = d[b];
     }
     out.insert(out.end(), dg.begin(), dg.end());
+    // even-odd tables of D^T (the assembly kernel's last contraction; at the end: the earlier offsets stay what they are)
+    std::vector< double > Dt(size_t(nq) * n);
+    for (int b = 0; b < n; ++b)
+        for (int q = 0; q < nq; ++q)
+            Dt[q * n + b] = D[b * nq + q];
+    append(Dt, nq, n, true);
     return out;
 }
 } // namespace l3k::host
