@@ -11,7 +11,7 @@
 //    which overlaps one wave's LDS phases with another wave's FMA phases (with 256-thread workgroups in lockstep the two
 //    pipes were each ~35 % busy and serialised: profiles/r01_pmc_fast_v2b_compute_only.txt);
 //  * every lane owns ONE 1-D pencil of ALL fields in registers, so each sweep is register-only FMAs with the even-odd
-//    decomposition (the reference's own flop cut, algsys/SumFactorization.hpp:88-343: 37 instead of 49 instructions per
+//    decomposition (the reference's own flop cut, algsys/SumFactorization.hpp:88-343: 34 instead of 49 instructions per
 //    7-point pencil); the LDS only carries the pencil re-orientations (two buffers per element), with the fields
 //    interleaved in pairs so that every LDS access is 16 bytes wide;
 //  * the global gather goes straight to registers one element ahead (node ids two ahead) and stays in flight behind the

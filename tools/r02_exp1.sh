@@ -3,6 +3,10 @@
 set -o pipefail
 OUT=gpurun_out/r02_exp1
 mkdir -p $OUT
+# the probes are built from their sources here (no binaries in the repository)
+for t in fp64_coissue fp64_issue lds_write_overlap; do
+  hipcc -O3 --offload-arch=gfx950 tools/$t.hip -o tools/$t || exit 1
+done
 timeout -k 10 120 tools/fp64_coissue > $OUT/fp64_coissue.log 2>&1 || { echo "coissue failed"; tail -5 $OUT/fp64_coissue.log; }
 cat $OUT/fp64_coissue.log
 ABL=$PWD/l3ster_amd/lib/libl3k_ablation.so
