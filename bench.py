@@ -160,19 +160,27 @@ def main():
     Y = torch.empty_like(X)
     op, native = None, False
     if use_dist:
-        # the exchange runs inside the library (l3k_mf_apply_dist: RCCL send / receive on its own stream, behind the C ABI);
-        # L3K_BENCH_TRANSPORT=torch, or a failed communicator set-up on any rank, selects the torch.distributed transport
-        ok = 0
-        if os.environ.get("L3K_BENCH_TRANSPORT", "native") == "native":
+        # Transport of the ghost exchange.  Default: torch.distributed P2P (batch_isend_irecv = RCCL send / receive over xGMI)
+        # around the split-phase C-ABI calls.  L3K_BENCH_TRANSPORT=native: the exchange inside the library (l3k_mf_apply_dist:
+        # RCCL groups on the library's own stream).  Its schedule is tested with several ranks through the in-process
+        # transport (tests/test_gpu_dist_cabi.py), but RCCL under it has only ever run as a self exchange on one GPU, so it
+        # stays opt-in until a run on two or more GPUs is on record.  Set-up in two steps so that no rank can fall out of a
+        # collective: (1) every rank checks locally, without communication, that RCCL loads and that its exchange lists are
+        # what the library takes; all ranks agree (MIN); (2) only then the collective part (broadcast of the unique id,
+        # ncclCommInitRank) runs, on all ranks or on none.
+        if os.environ.get("L3K_BENCH_TRANSPORT", "torch") == "native":
+            ok = 1
             try:
-                op = NativeDistributedOperator(mf, NativeHalo(ctx, part, U, rank, world))
-                ok = 1
+                NativeHalo.check_local(part)
             except Exception as exc:  # pragma: no cover
+                ok = 0
                 print(f"[bench rank {rank}] native halo unavailable ({exc}); torch.distributed transport", file=sys.stderr, flush=True)
-        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-        native = bool(agree.item())
-        if not native:
+            agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            native = bool(agree.item())
+        if native:
+            op = NativeDistributedOperator(mf, NativeHalo(ctx, part, U, rank, world))
+        else:
             op = DistributedOperator(mf, HaloPlan(part, U, dev))
     t_setup = time.perf_counter() - t_setup
 
@@ -214,6 +222,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # the dominant kernel, HIP events on the launch stream inside the timed region: one launch over all elements (one GPU), or
+    # the three launches of a partitioned apply (first interior half, border elements, second interior half) summed -- per
+    # timed step the MAX over the ranks (the ranks that own Dirichlet faces run longer)
+    if native:
+        kernel_times = [sum(op.timing_get(i)) for i in range(args.steps)]
+    else:
+        kernel_times = [sum(a.elapsed_time(b) for a, b in e) for e in ev]
+    if use_dist:
+        kt = torch.tensor(kernel_times, dtype=torch.float64, device=dev)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kernel_times = kt.tolist()
+    ms = float(np.median(kernel_times))  # median of the timed steps
     global_dofs = part.n_global_nodes * U
     value = global_dofs * args.steps / elapsed
     bpd = algorithmic_bytes_per_dof(p, U)
@@ -228,14 +248,7 @@ def main():
                    "alpha": 1.0, "beta": 0.0, "setup_s": round(t_setup, 2)},
     }
     if rank == 0:
-        # the dominant kernel of rank 0, HIP events on the launch stream inside the timed region: one launch over all
-        # elements (one GPU), or the three launches of a partitioned apply (first interior half, border elements, second
-        # interior half) summed; algorithmic bytes = 17.81 B per dof of the elements they process
-        if native:
-            kernel_times = [sum(op.timing_get(i)) for i in range(args.steps)]
-        else:
-            kernel_times = [sum(a.elapsed_time(b) for a, b in e) for e in ev]
-        ms = float(np.median(kernel_times))  # median of the timed steps
+        # algorithmic bytes = 17.81 B per dof of the elements one rank's launches process
         n_launch_elems = part.n_elems
         launch_dofs = n_launch_elems * p ** 3 * U if op is not None else global_dofs
         alg_bytes = bpd * launch_dofs
@@ -245,7 +258,7 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": traffic_source,
-                              "kernel": "sumfactFastKernel" + (" (rank 0: the three element launches of the partitioned apply, summed)" if op is not None else ""),
+                              "kernel": "sumfactFastKernel" + (" (the three element launches of the partitioned apply, summed; per step the max over the ranks)" if op is not None else ""),
                               "transport": None if op is None else ("l3k_mf_apply_dist (RCCL inside the library)" if native else "torch.distributed P2P"),
                               "kernel_ms": ms, "kernel_ms_mean": float(np.mean(kernel_times)), "kernel_ms_stat": "median of the timed launches",
                               "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
@@ -260,25 +273,26 @@ def main():
             # (checksums instead of 15 MB per matrix); outside the timed region.  Default algorithm: sum-factorised assembly
             # (device/assemble.hpp: ~58 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
             # the FP64 matrix cores (4 523 MFLOP per element using symmetry), the formulation the reference computes
-            batch, reps = 512, 3
-            apart = system.CubePartition(8, p, perturb=0.1)
-            amesh = system.DeviceMesh(ctx, apart, U)
-            amf = system.MatrixFreeSystem(amesh, kid, [1.0, 1.0])
+            # sum-factorised kernel: the FULL sweep over the benchmark mesh (args.ne^3 elements; 262 144 at 64^3), in batches
+            # of 512; the dense product (28x slower) on three batches of the same mesh
+            batch = 512
+            amf = mf
 
-            def assembly_rate():
+            def assembly_rate(n_elems):
                 amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
                 a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a0.record()
-                for _ in range(reps):
-                    amf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True)
+                for first in range(0, n_elems, batch):
+                    amf.local_assemble(first, min(batch, n_elems - first), want_K=False, want_F=False, want_checksum=True)
                 a1.record()
                 torch.cuda.synchronize()
-                return batch / (a0.elapsed_time(a1) / reps * 1e-3)
+                return n_elems / (a0.elapsed_time(a1) * 1e-3)
 
-            rate = assembly_rate()
+            n_sweep = part.n_elems
+            rate = assembly_rate(n_sweep)
             os.environ["L3K_ASSEMBLE_DENSE"] = "1"
             try:
-                rate_dense = assembly_rate()
+                rate_dense = assembly_rate(min(3 * batch, n_sweep))
             finally:
                 os.environ.pop("L3K_ASSEMBLE_DENSE", None)
             nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * 7
@@ -286,8 +300,9 @@ def main():
             sf_flops = SUMFACT_ASSEMBLY_FLOP_PER_ELEM  # executed by the sum-factorised kernel (order 6, U = 4, E = 7)
             result["assembled_path"] = {"metric": "element-matrices/s for assembled path (LocalAssembly, Diffusion3D, hex p=6)",
                                         "value": rate, "unit": "element matrices/s", "batch": batch,
+                                        "sample": f"full streaming sweep over the benchmark mesh: {n_sweep} elements (checksums on the device)",
                                         "algorithm": "sum-factorised assembly on index pairs (O(n^7) per pair of unknowns), FP64 vector pipe",
-                                        "roofline": {"bound": "mfma", "achieved": rate * sf_flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                        "roofline": {"bound": "fp64-valu", "achieved": rate * sf_flops / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                                                      "frac": rate * sf_flops / 1e12 / 78.6,
                                                      "flops": "executed: %.1f MFLOP per element; FP64 matrix and vector pipes are one pipe "
                                                               "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)"
@@ -298,7 +313,7 @@ def main():
                                                                            "peak": 78.6, "unit": "TFLOP/s",
                                                                            "frac": rate_dense * dense_flops / 1e12 / 78.6,
                                                                            "flops": "symmetric half, 2*K*N*(N+1)/2 per element"}}}
-            del amf, amesh, apart
+            del amf
             # BASELINE.json configs[1]: the same apply at order 4 on the same 64^3 mesh (outside the timed region)
             p4 = 4
             part4 = system.CubePartition(args.ne, p4, perturb=0.1)

@@ -327,11 +327,38 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
  * l3k_halo_export_add: owners' rows += ghost rows           (sharer -> owner add; per neighbour in list order)
  * l3k_mf_apply_dist:   y <- alpha A x + beta y on the owned rows, x and y [ncols][ld] over the owned rows only: scale, pack,
  *   post import || first half of the interior elements, border elements, post export || second half of the interior
- *   elements, unpack-add, Dirichlet rows.  Every call returns with the work queued on the context's stream. */
+ *   elements, unpack-add, Dirichlet rows.  Every call returns with the work queued on the context's stream.
+ *
+ * The transport is a small function table (RCCL unless the caller brings one): a group of point-to-point messages between
+ * `begin` and `end`, every message on the given HIP stream (the halo's communication stream), complete in stream order behind
+ * `end` -- the contract of ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd.  l3k_halo_create_transport takes any table
+ * (an MPI-with-device-pointers host, a test double); `destroy` (may be NULL) is called with `user` when the halo is destroyed
+ * (not if its creation fails).  The library's own second implementation is the IN-PROCESS transport: the ranks are threads
+ * of one process, each with its own context and stream on one GPU or on several, and a message is a device-to-device copy
+ * ordered by events -- for single-process multi-GPU hosts, and the seam through which the tests run l3k_mf_apply_dist with
+ * several ranks on a one-GPU box (tests/MpiImportExportTest.cpp:17-136 runs the reference's exchange on np in {1, 2, 4}).
+ * l3k_inproc_group_create(world): the shared mailboxes; l3k_inproc_transport(group, rank, &table): rank's table (the group
+ * owns it and must outlive the halos). */
+typedef struct l3k_halo_transport
+{
+    void* user;
+    int (*group_begin)(void* user);
+    int (*send)(void* user, const double* d_buf, size_t count, int peer, void* hip_stream);
+    int (*recv)(void* user, double* d_buf, size_t count, int peer, void* hip_stream);
+    int (*group_end)(void* user, void* hip_stream);
+    void (*destroy)(void* user);
+} l3k_halo_transport;
+typedef struct l3k_inproc_group l3k_inproc_group;
 typedef struct l3k_halo l3k_halo;
 int     l3k_halo_unique_id(char* id128);
 int     l3k_halo_create(l3k_ctx* ctx, const char* id128, int rank, int world, int dofs_per_node, int n_nbrs, const int* nbr_rank,
                         const int64_t* send_offsets, const int32_t* send_nodes, const int64_t* ghost_offsets, l3k_halo** out);
+int     l3k_halo_create_transport(l3k_ctx* ctx, const l3k_halo_transport* transport, int rank, int world, int dofs_per_node,
+                                  int n_nbrs, const int* nbr_rank, const int64_t* send_offsets, const int32_t* send_nodes,
+                                  const int64_t* ghost_offsets, l3k_halo** out);
+int     l3k_inproc_group_create(int world, l3k_inproc_group** out);
+int     l3k_inproc_group_destroy(l3k_inproc_group* group);
+int     l3k_inproc_transport(l3k_inproc_group* group, int rank, l3k_halo_transport* out);
 int     l3k_halo_destroy(l3k_halo* halo);
 int64_t l3k_halo_n_ghost_dofs(const l3k_halo* halo);
 int     l3k_halo_import(l3k_halo* halo, const double* d_owned, size_t ld, int ncols, double* d_ghost, size_t ldg);

@@ -53,6 +53,17 @@ c_uint64_p = C.POINTER(C.c_uint64)
 c_uint16_p = C.POINTER(C.c_uint16)
 
 
+class HaloTransport(C.Structure):
+    """l3k_halo_transport: group begin / send / recv / group end (+ destroy) over device pointers and a HIP stream."""
+    GROUP_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    GROUP_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+    DESTROY = C.CFUNCTYPE(None, C.c_void_p)
+    _fields_ = [("user", C.c_void_p), ("group_begin", GROUP_BEGIN), ("send", SEND), ("recv", RECV), ("group_end", GROUP_END),
+                ("destroy", DESTROY)]
+
+
 class MeshFileElems(C.Structure):
     _fields_ = [("n", C.c_size_t), ("nodes", c_uint64_p), ("verts", c_double_p), ("ids", c_uint64_p)]
 
@@ -106,6 +117,11 @@ SIGNATURES = {
     "l3k_halo_unique_id": (C.c_int, [C.c_char_p]),
     "l3k_halo_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int64_p, c_int32_p, c_int64_p,
                                   C.POINTER(_vp)]),
+    "l3k_halo_create_transport": (C.c_int, [_vp, C.POINTER(HaloTransport), C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int64_p,
+                                            c_int32_p, c_int64_p, C.POINTER(_vp)]),
+    "l3k_inproc_group_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "l3k_inproc_group_destroy": (C.c_int, [_vp]),
+    "l3k_inproc_transport": (C.c_int, [_vp, C.c_int, C.POINTER(HaloTransport)]),
     "l3k_halo_destroy": (C.c_int, [_vp]),
     "l3k_halo_n_ghost_dofs": (C.c_int64, [_vp]),
     "l3k_halo_import": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t]),

@@ -315,7 +315,7 @@ int bndArgs(const l3k_bnd* b, int which, int ncols, l3k::dev::ElemArgs& a)
     return 0;
 }
 // the launch ranges of a side call: the caller's range, or in deterministic mode one launch per colour of the classes it
-// covers (sides of one colour share no node: the order of the additions to a row is the order of the launches)
+// covers (the ELEMENTS of the sides of one colour share no node: the order of the additions to a row is the order of the launches)
 template < typename F >
 int forEachSideRange(const l3k_bnd* b, int which, l3k::dev::ElemArgs& a, F&& launch)
 {
@@ -652,7 +652,7 @@ int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
         ctx->deterministic = std::atoi(e) != 0;
     // the context's own device buffers are allocated here, with its device current: a later call may come from a thread
     // whose current device is another one (several contexts in one process: thread-emulated ranks, a multi-GPU C++ host)
-    if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 8 * 128) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 9 * 128) != hipSuccess ||
         hipMalloc(reinterpret_cast< void** >(&ctx->red_ws), sizeof(double) * 2 * l3k_cg_blocks) != hipSuccess)
     {
         delete ctx;
@@ -1435,23 +1435,25 @@ int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpar
     b->n_faces = n_faces;
     if (ctx->deterministic)
     {
-        // greedy colouring of the sides by their four corner nodes (two sides of a conforming mesh that share a node share
-        // a corner), class by class; the lists are stored in (class, colour) order
+        // greedy colouring of the sides by ALL EIGHT corner nodes of their elements: the side kernel scatter-adds over every
+        // node of the element (the normal derivative couples all of them, device/boundary.hpp), so two sides may share a
+        // colour only if their elements share no node -- for conforming hexes: no corner.  (Colouring by the side's own four
+        // corners let the z- side of a corner element and the x- side of the element stacked on it into one launch.)
+        // Class by class; the lists are stored in (class, colour) order
         if (!mesh->det_built)
         {
             setError("deterministic mode was enabled after this mesh was created: create the mesh with the mode on");
             return -1;
         }
-        static constexpr int side_corners[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 4, 5}, {2, 3, 6, 7}, {0, 2, 4, 6}, {1, 3, 5, 7}};
         std::unordered_map< uint32_t, uint64_t > used;
         std::vector< uint8_t >                   colour(fe.size());
         int                                      n_colours = 0;
         for (size_t i = 0; i < fe.size(); ++i)
         {
             uint64_t taken = 0;
-            for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < 8; ++v)
             {
-                const auto it = used.find(mesh->det_corner_nodes[size_t(fe[i]) * 8 + side_corners[fs[i]][v]]);
+                const auto it = used.find(mesh->det_corner_nodes[size_t(fe[i]) * 8 + v]);
                 if (it != used.end())
                     taken |= it->second;
             }
@@ -1465,8 +1467,8 @@ int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kpar
             }
             colour[i] = uint8_t(c);
             n_colours = std::max(n_colours, c + 1);
-            for (int v = 0; v < 4; ++v)
-                used[mesh->det_corner_nodes[size_t(fe[i]) * 8 + side_corners[fs[i]][v]]] |= uint64_t(1) << c;
+            for (int v = 0; v < 8; ++v)
+                used[mesh->det_corner_nodes[size_t(fe[i]) * 8 + v]] |= uint64_t(1) << c;
         }
         std::vector< size_t > order(fe.size());
         for (size_t i = 0; i < order.size(); ++i)

@@ -8,6 +8,8 @@
 // sumIntoLocalValues per row batch -- not one call per element row.
 #include "objects.hpp"
 
+#include <cstdlib>
+
 namespace
 {
 struct ScatterArgs
@@ -21,19 +23,19 @@ struct ScatterArgs
     size_t          ldr;
     unsigned long long* n_missing;
     int64_t         first, count;
-    int             NN, U, dpn, n_rhs, skip_dirichlet;
+    int             NN, dpn, n_rhs, skip_dirichlet, U_rt;
     int             field_inds[l3k::dev::max_unknowns];
 };
 
-// one wave per (element, local row): the row of K_e is read contiguously; every entry finds its position in the CSR row by
-// binary search over the row's sorted column indices and is added atomically (elements sharing the row run concurrently)
-__global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a)
+// The round-2 form, kept behind L3K_SCATTER_PER_ENTRY=1 as the cross-check (tests) and the baseline (tools/bench_assembled_pipeline.py):
+// one wave per (element, local row), a binary search per ENTRY
+__global__ __launch_bounds__(64) void assembledScatterPerEntryKernel(const ScatterArgs a)
 {
-    const int     Nd   = a.NN * a.U;
+    const int     Nd   = a.NN * a.U_rt;
     const int64_t e    = blockIdx.x / Nd; // element of the batch
     const int     i    = int(blockIdx.x - e * Nd);
     const uint32_t* en = a.elem_nodes + (a.first + e) * a.NN;
-    const int64_t row  = int64_t(en[i / a.U]) * a.dpn + a.field_inds[i % a.U];
+    const int64_t row  = int64_t(en[i / a.U_rt]) * a.dpn + a.field_inds[i % a.U_rt];
     if (a.skip_dirichlet && a.dirichlet && a.dirichlet[row])
         return;
     const int lane = threadIdx.x;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a
     unsigned       missing = 0;
     for (int j = lane; j < Nd; j += 64)
     {
-        const int64_t col = int64_t(en[j / a.U]) * a.dpn + a.field_inds[j % a.U];
+        const int64_t col = int64_t(en[j / a.U_rt]) * a.dpn + a.field_inds[j % a.U_rt];
         if (a.skip_dirichlet && a.dirichlet && a.dirichlet[col])
             continue;
         int64_t lo = rb, hi = re; // first position with col_ind >= col
@@ -62,6 +64,85 @@ __global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a
             unsafeAtomicAdd(a.values + lo, Kr[j]);
         else
             ++missing; // (Tpetra's sumIntoLocalValues skips entries outside the graph and reports how many it took)
+    }
+    if (missing && a.n_missing)
+        atomicAdd(a.n_missing, static_cast< unsigned long long >(missing));
+}
+
+// first position in [lo, hi) with col_ind >= col
+__device__ __forceinline__ int64_t lowerBound(const int32_t* __restrict__ col_ind, int64_t lo, int64_t hi, int64_t col)
+{
+    while (lo < hi)
+    {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col_ind[mid] < col)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// One wave per (element, ROW NODE b): the U rows (b, u) of K_e, the lanes over the Nd consecutive ENTRIES of a row, so that a
+// wave-instruction reads 512 contiguous bytes of K_e and its atomic adds fall on runs of neighbouring CSR values (dense
+// 64-byte requests: the memory-side atomic units are a request-rate limit -- a first form with one column NODE per lane,
+// i.e. atomics at a stride of U values, ran at 0.6 x the rate of the per-entry kernel above although it searched 16 x less).
+// The position of an entry's column in the CSR row of (b, u = 0) is found by ONE binary search and reused for the rows
+// u = 1 .. U-1: the rows of one node carry the same columns in a finite-element graph; the candidate position is checked
+// against col_ind and a row without that structure falls back to its own search (same results).
+template < int U >
+__global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a)
+{
+    const int       Nd   = a.NN * U;
+    const int64_t   e    = blockIdx.x / a.NN; // element of the batch
+    const int       b    = int(blockIdx.x - e * a.NN);
+    const uint32_t* en   = a.elem_nodes + (a.first + e) * a.NN;
+    const int       lane = threadIdx.x;
+    const int64_t   nb   = int64_t(en[b]) * a.dpn;
+    int64_t         row[U], rb[U], re[U];
+    bool            live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+        row[u]  = nb + a.field_inds[u];
+        live[u] = !(a.skip_dirichlet && a.dirichlet && a.dirichlet[row[u]]);
+    }
+    if (a.F && a.rhs && lane < a.n_rhs * U)
+    {
+        const int r = lane / U, u = lane - r * U;
+        if (live[u])
+            unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row[u], a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
+    }
+    if (!a.K || !a.values)
+        return;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+        rb[u] = a.row_ptr[row[u]];
+        re[u] = a.row_ptr[row[u] + 1];
+    }
+    const double* Kb      = a.K + (e * Nd + int64_t(b) * U) * Nd; // rows (b, 0 .. U-1)
+    unsigned      missing = 0;
+    for (int j = lane; j < Nd; j += 64)
+    {
+        const int     bp  = j / U;
+        const int64_t col = int64_t(en[bp]) * a.dpn + a.field_inds[j - bp * U];
+        if (a.skip_dirichlet && a.dirichlet && a.dirichlet[col])
+            continue;
+        const int64_t rel = lowerBound(a.col_ind, rb[0], re[0], col) - rb[0]; // the entry's one search
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            if (!live[u])
+                continue;
+            int64_t pos = rb[u] + rel;
+            if (u > 0 && !(pos < re[u] && a.col_ind[pos] == col))
+                pos = lowerBound(a.col_ind, rb[u], re[u], col);
+            if (pos < re[u] && a.col_ind[pos] == col)
+                unsafeAtomicAdd(a.values + pos, Kb[int64_t(u) * Nd + j]);
+            else
+                ++missing; // (Tpetra's sumIntoLocalValues skips entries outside the graph and reports how many it took)
+        }
     }
     if (missing && a.n_missing)
         atomicAdd(a.n_missing, static_cast< unsigned long long >(missing));
@@ -105,18 +186,18 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
     if (count == 0 || (!d_K && !d_F))
         return 0;
     L3K_HIP(hipSetDevice(mf->ctx->device));
-    const int     N1 = m->order + 1, NN = N1 * N1 * N1, Nd = NN * mf->kp.n_unknowns;
-    const int64_t blocks = count * Nd;
+    const int     N1 = m->order + 1, NN = N1 * N1 * N1;
+    const int64_t blocks = count * NN;
     if (blocks > int64_t(0x7fffffff))
     {
         setError("batch too large: %lld element rows in one launch", (long long)blocks);
         return -1;
     }
     hipStream_t         s       = mf->ctx->stream;
-    unsigned long long* d_count = nullptr;
+    unsigned long long* d_count = nullptr; // (a counter of the context: no allocation per call)
     if (n_missing)
     {
-        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&d_count), sizeof(unsigned long long)));
+        d_count = mf->ctx->missCounter();
         L3K_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
     }
     ScatterArgs a{};
@@ -133,20 +214,41 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
     a.first          = first;
     a.count          = count;
     a.NN             = NN;
-    a.U              = mf->kp.n_unknowns;
     a.dpn            = m->dofs_per_node;
     a.n_rhs          = mf->n_rhs;
     a.skip_dirichlet = skip_dirichlet;
     for (int u = 0; u < l3k::dev::max_unknowns; ++u)
         a.field_inds[u] = mf->field_inds[u];
-    hipLaunchKernelGGL(assembledScatterKernel, dim3(unsigned(blocks)), dim3(64), 0, s, a);
+    a.U_rt = mf->kp.n_unknowns;
+    if (std::getenv("L3K_SCATTER_PER_ENTRY"))
+    {
+        const int64_t rows = count * NN * mf->kp.n_unknowns;
+        if (rows > int64_t(0x7fffffff))
+        {
+            setError("batch too large: %lld element rows in one launch", (long long)rows);
+            return -1;
+        }
+        hipLaunchKernelGGL(assembledScatterPerEntryKernel, dim3(unsigned(rows)), dim3(64), 0, s, a);
+    }
+    else
+    switch (mf->kp.n_unknowns)
+    {
+    case 1: hipLaunchKernelGGL(assembledScatterKernel< 1 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(assembledScatterKernel< 2 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(assembledScatterKernel< 3 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(assembledScatterKernel< 4 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(assembledScatterKernel< 5 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 6: hipLaunchKernelGGL(assembledScatterKernel< 6 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 7: hipLaunchKernelGGL(assembledScatterKernel< 7 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(assembledScatterKernel< 8 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+    default: setError("l3k_assembled_scatter: %d unknowns not supported (1..8)", mf->kp.n_unknowns); return -1;
+    }
     L3K_HIP(hipGetLastError());
     if (n_missing)
     {
         unsigned long long h = 0;
         L3K_HIP(hipMemcpyAsync(&h, d_count, sizeof h, hipMemcpyDeviceToHost, s));
         L3K_HIP(hipStreamSynchronize(s));
-        L3K_HIP(hipFree(d_count));
         *n_missing = int64_t(h);
     }
     return 0;

@@ -388,7 +388,7 @@ __device__ __forceinline__ int opaqueOffset(int x)
 }
 template < typename K, int P, int NQ >
 __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
-                                                                                       int64_t elem0)
+                                                                                       int64_t elem0, int xcd_group)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
@@ -406,8 +406,28 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     double* const            A  = Pt + 4 * N2 * NQ; // [PAIRS][9][NQ (qz)][AROW (qy, padded)]
 
     const int     tid = threadIdx.x;
-    const int64_t el  = blockIdx.y;
-    int           u = 0, rem = blockIdx.x; // unknown pair of this workgroup: u' <= u
+    // Workgroup -> (element, unknown pair).  Workgroups are dealt round-robin to the 8 XCDs: with xcd_group the U (U + 1) / 2
+    // workgroups of ONE element have the same index modulo 8, i.e. sit on one XCD and share its L2 -- in stored mode every
+    // 64-byte line of K_e receives its 8 entries from 4 pair-workgroups (the unknown u' is the fastest index of a row), so
+    // they should at least meet in one L2.  Otherwise blockIdx = pair + NP * element.
+    constexpr int NP = U * (U + 1) / 2;
+    int64_t       el;
+    int           rem;
+    if (xcd_group)
+    {
+        const int64_t chunk = blockIdx.x / (8 * NP);
+        const int     w     = int(blockIdx.x - chunk * (8 * NP));
+        el                  = chunk * 8 + (w & 7);
+        rem                 = w >> 3;
+        if (el >= a.elem_count)
+            return;
+    }
+    else
+    {
+        el  = blockIdx.x / NP;
+        rem = int(blockIdx.x - el * NP);
+    }
+    int u = 0; // unknown pair of this workgroup: u' <= u
     while (rem > u)
     {
         rem -= u + 1;
@@ -655,50 +675,53 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     const size_t  ldc = sizeof(double) * (size_t(5 * K::params.n_fields) * M * M * M + 24);
     auto          kc  = assembleCoeffKernel< K, P, NQ >;
     auto          kg  = assembleGemmKernel< K, P, NQ >;
-    static bool   attr_set = false;
-    if (!attr_set)
+    // the dynamic-LDS attributes of the three kernels are set once PER DEVICE, under a lock (several contexts of one
+    // process may sit on different GPUs)
+    using S = SfAsmCfg< P, NQ >;
     {
-        if (hipFuncSetAttribute(reinterpret_cast< const void* >(kc), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldc)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast< const void* >(kg), hipFuncAttributeMaxDynamicSharedMemorySize, int(C::lds)) != hipSuccess)
+        static bool       attr_set[64] = {};
+        static std::mutex attr_mutex;
+        int               dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64)
         {
-            setError("hipFuncSetAttribute failed for the assembly kernels");
+            setError("device index %d not supported", dev);
             return -3;
         }
-        attr_set = true;
+        std::lock_guard< std::mutex > lock{attr_mutex};
+        if (!attr_set[dev])
+        {
+            bool ok = hipFuncSetAttribute(reinterpret_cast< const void* >(kc), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldc)) == hipSuccess &&
+                      hipFuncSetAttribute(reinterpret_cast< const void* >(kg), hipFuncAttributeMaxDynamicSharedMemorySize, int(C::lds)) == hipSuccess;
+            if constexpr (S::feasible)
+                ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess;
+            if (!ok)
+            {
+                setError("hipFuncSetAttribute failed for the assembly kernels");
+                return -3;
+            }
+            attr_set[dev] = true;
+        }
     }
     double* cbuf = a.workspace; // coeffStride * nq^3 doubles per element, + 1 flag
     hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
-    using S = SfAsmCfg< P, NQ >;
     // the sum-factorised kernel unless it does not fit or L3K_ASSEMBLE_DENSE=1 asks for the dense MFMA product (cross-check)
     const bool dense = !S::feasible || std::getenv("L3K_ASSEMBLE_DENSE") != nullptr;
     if constexpr (S::feasible)
         if (!dense)
         {
             auto ks = assembleSumfactKernel< K, P, NQ >;
-            // (the dynamic-LDS attribute is set once per device, under a lock)
-            static bool       attr_set[64] = {};
-            static std::mutex attr_mutex;
-            int               dev = 0;
-            (void)hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64)
+            constexpr int NP        = U * (U + 1) / 2;
+            const int     xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
+            const int64_t n_blocks  = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
+            if (n_blocks > int64_t(0x7fffffff))
             {
-                setError("device index %d not supported", dev);
-                return -3;
+                setError("assembly batch too large: %lld workgroups", (long long)n_blocks);
+                return -1;
             }
-            {
-                std::lock_guard< std::mutex > lock{attr_mutex};
-                if (!attr_set[dev])
-                {
-                    if (hipFuncSetAttribute(reinterpret_cast< const void* >(ks), hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) != hipSuccess)
-                    {
-                        setError("hipFuncSetAttribute failed for the sum-factorised assembly kernel");
-                        return -3;
-                    }
-                    attr_set[dev] = true;
-                }
-            }
-            hipLaunchKernelGGL(ks, dim3(U * (U + 1) / 2, static_cast< unsigned >(a.elem_count)), dim3(S::threads), S::lds, stream, a, cbuf,
-                               int64_t(a.elem_begin_out));
+            hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(S::threads), S::lds, stream, a, cbuf,
+                               int64_t(a.elem_begin_out), xcd_group);
         }
     if (dense)
         hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,

@@ -110,7 +110,9 @@ struct l3k_ctx
     // (no two elements of a launch share a node), so every row of y receives its contributions in a fixed order
     bool        deterministic = false;
     double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
-    uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes)
+    uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes) + one more line:
+    // the counter of l3k_assembled_scatter's entries outside the graph (no allocation per call)
+    unsigned long long* missCounter() const { return reinterpret_cast< unsigned long long* >(work_counters + 8 * 32); }
     ~l3k_ctx()
     {
         if (red_ws)

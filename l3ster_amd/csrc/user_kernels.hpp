@@ -179,6 +179,28 @@ struct Robin3D
     }
 };
 
+// Boundary kernel with derivative operators (synthetic): n . grad T + c d(q_x)/dx + h T = g -- fills A1..A3, so the side
+// kernel's normal-derivative path (every node of the element takes part) is exercised
+struct NormalFlux3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1, .n_unknowns = 4};
+    double                        h = 1., g = 0., c = 0.5;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [vals, ders, point, normal] = in;
+        auto& [operators, rhs]                  = out;
+        auto& [A0, A1, A2, A3]                  = operators;
+        A0(0, 0) = h;
+        A1(0, 0) = normal[0];
+        A2(0, 0) = normal[1];
+        A3(0, 0) = normal[2];
+        A1(0, 1) = c;
+        rhs[0]   = g;
+    }
+};
+
 // ---- residual kernels (integrals, L2 norms): out[n_equations] from the interpolated fields ------------------------
 // benchmarks/Diffusion3D.hpp:81-103: residuals of the first-order diffusion system for the fields (T, qx, qy, qz)
 struct Diffusion3DError
@@ -247,7 +269,8 @@ struct Unit3D
 // boundary equation kernels (ids continue the numbering above; 5 is the 2-D adiabatic kernel of the CPU oracle)
 #define L3K_FOR_EACH_BOUNDARY_KERNEL(X)                                                                                \
     X(6, ::l3k::kernels::Adiabatic3D, "adiabatic3d")                                                                   \
-    X(7, ::l3k::kernels::Robin3D, "robin3d")
+    X(7, ::l3k::kernels::Robin3D, "robin3d")                                                                           \
+    X(9, ::l3k::kernels::NormalFlux3D, "normalflux3d")
 
 // residual kernels (own id space; 1 and 3 are the 2-D kernels of the CPU oracle)
 #define L3K_FOR_EACH_RESIDUAL_KERNEL(X)                                                                                \
@@ -286,7 +309,11 @@ struct Unit3D
     X(::l3k::kernels::Robin3D, 2, 3, 1)                                                                                \
     X(::l3k::kernels::Robin3D, 2, 3, 2)                                                                                \
     X(::l3k::kernels::Robin3D, 3, 7, 1)                                                                                \
-    X(::l3k::kernels::Robin3D, 4, 5, 1)
+    X(::l3k::kernels::Robin3D, 4, 5, 1)                                                                                \
+    X(::l3k::kernels::NormalFlux3D, 2, 3, 1)                                                                           \
+    X(::l3k::kernels::NormalFlux3D, 2, 3, 2)                                                                           \
+    X(::l3k::kernels::NormalFlux3D, 3, 7, 1)                                                                           \
+    X(::l3k::kernels::NormalFlux3D, 4, 5, 1)
 
 // (functor, order p, nq); computeNormL2 doubles the quadrature orders: nq = 2p+1 for the default options
 #define L3K_FOR_EACH_RESIDUAL_INSTANCE(X)                                                                              \

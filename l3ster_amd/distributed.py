@@ -194,17 +194,58 @@ class DistributedOperator:
         return diag, rhs
 
 
+class InprocGroup:
+    """The mailboxes of the library's in-process transport (l3k_inproc_group_*): the ranks are threads of this process, each
+    with its own context and stream, on one GPU or on several."""
+
+    def __init__(self, world):
+        import ctypes as C
+        from . import capi
+        self._g = C.c_void_p()
+        capi.check(capi.load().l3k_inproc_group_create(world, C.byref(self._g)))
+        self.world = world
+
+    def table(self, rank):
+        import ctypes as C
+        from . import capi
+        t = capi.HaloTransport()
+        capi.check(capi.load().l3k_inproc_transport(self._g, rank, C.byref(t)))
+        return t
+
+    def __del__(self):
+        try:
+            from . import capi
+            if getattr(self, "_g", None):
+                capi.load().l3k_inproc_group_destroy(self._g)
+                self._g = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class NativeHalo:
     """The exchange lists of one rank handed to the library, which runs the neighbour exchange itself through RCCL on a
     stream of its own (l3k_halo_*, include/l3k.h): what a C++ host of the reference would use instead of its MPI
     Import / Export.  unique_id: the 128 bytes of l3k_halo_unique_id from one rank (None: rank 0 draws it and it is
     broadcast over torch.distributed, which must then be initialised when world > 1)."""
 
-    def __init__(self, ctx, part, dofs_per_node, rank=0, world=1, unique_id=None, group=None):
+    @staticmethod
+    def check_local(part):
+        """What can fail on ONE rank before any collective of the set-up runs, checked without communication: RCCL loads
+        (l3k_halo_unique_id dlopens it) and the ghost ranges are contiguous in neighbour order.  Callers agree on the result
+        (all-reduce MIN) before any of them constructs a NativeHalo, so that no rank falls out of the collectives."""
+        import ctypes as C
+        from . import capi
+        capi.check(capi.load().l3k_halo_unique_id(C.create_string_buffer(128)))
+        for (g0, _), prev in zip(part.ghost_ranges[1:], part.ghost_ranges[:-1]):
+            if g0 != prev[1]:
+                raise ValueError("ghost ranges must be contiguous in neighbour order")
+
+    def __init__(self, ctx, part, dofs_per_node, rank=0, world=1, unique_id=None, group=None, transport=None):
+        """transport: None (RCCL), an InprocGroup (ranks are threads of this process), or a capi.HaloTransport table."""
         import ctypes as C
         from . import capi
         lib = capi.load()
-        if unique_id is None:
+        if transport is None and unique_id is None:
             buf = C.create_string_buffer(128)
             if rank == 0:
                 capi.check(lib.l3k_halo_unique_id(buf))
@@ -223,16 +264,24 @@ class NativeHalo:
                 raise ValueError("ghost ranges must be contiguous in neighbour order")
         nr = np.asarray(part.nbr_rank, dtype=np.int32)
         self._h = C.c_void_p()
-        capi.check(lib.l3k_halo_create(ctx._h, unique_id, rank, world, dofs_per_node, nn, nr.ctypes.data_as(capi.c_int_p),
-                                       so.ctypes.data_as(capi.c_int64_p), sn.ctypes.data_as(capi.c_int32_p),
-                                       go.ctypes.data_as(capi.c_int64_p), C.byref(self._h)))
+        lists = (nn, nr.ctypes.data_as(capi.c_int_p), so.ctypes.data_as(capi.c_int64_p), sn.ctypes.data_as(capi.c_int32_p),
+                 go.ctypes.data_as(capi.c_int64_p), C.byref(self._h))
+        if transport is None:
+            capi.check(lib.l3k_halo_create(ctx._h, unique_id, rank, world, dofs_per_node, *lists))
+        else:
+            table = transport.table(rank) if isinstance(transport, InprocGroup) else transport
+            self._transport = transport  # (the group / the callbacks must outlive the halo)
+            capi.check(lib.l3k_halo_create_transport(ctx._h, C.byref(table), rank, world, dofs_per_node, *lists))
         self.ctx = ctx
 
     def __del__(self):
-        from . import capi
-        if getattr(self, "_h", None) and capi is not None:
-            capi.load().l3k_halo_destroy(self._h)
-            self._h = None
+        try:
+            from . import capi
+            if getattr(self, "_h", None):
+                capi.load().l3k_halo_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class NativeDistributedOperator:

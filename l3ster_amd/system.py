@@ -22,6 +22,7 @@ KERNEL_ADVDIFF3D = 4
 KERNEL_MASS3D = 8  # A0 = I: known answers for w * detJ
 KERNEL_ADIABATIC3D = 6  # boundary equation kernels
 KERNEL_ROBIN3D = 7
+KERNEL_NORMALFLUX3D = 9  # boundary kernel with derivative operators (A1..A3)
 RESIDUAL_DIFFUSION3D_ERROR = 0
 RESIDUAL_LINEAR3D_ERROR = 2
 RESIDUAL_UNIT3D = 4

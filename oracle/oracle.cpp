@@ -335,6 +335,20 @@ void kRobin3D(const KIn& in, KOut& o)
     o.f(0)        = h * tinf;
 }
 
+// Boundary kernel WITH derivative operators (synthetic): n . grad T + c d(q_x)/dx + h T = g on the side; the normal
+// derivative couples every node of the element, which is what the side path's A1..A3 branch and the deterministic
+// mode's colouring by element have to get right.  kp = {h, g, c}
+void kNormalFlux3D(const KIn& in, KOut& o)
+{
+    const double h = in.kp ? in.kp[0] : 1., g = in.kp ? in.kp[1] : 0., c = in.kp ? in.kp[2] : 0.5;
+    o.op(0, 0, 0) = h;
+    o.op(1, 0, 0) = in.normal[0];
+    o.op(2, 0, 0) = in.normal[1];
+    o.op(3, 0, 0) = in.normal[2];
+    o.op(1, 0, 1) = c;
+    o.f(0)        = g;
+}
+
 // Mass-type kernel (A0 = I, rhs = (1, 2)): twin of l3k::kernels::Mass3D, the known answer for w * detJ in the domain path
 void kMass3D(const KIn&, KOut& o)
 {
@@ -360,7 +374,8 @@ const KernelEntry* getKernel(int id)
                                         {{2, 1, 3, 0}, kAdiabatic2D, true},
                                         {{3, 1, 4, 0}, kAdiabatic3D, true},
                                         {{3, 1, 4, 0}, kRobin3D, true},
-                                        {{3, 2, 2, 0}, kMass3D}};
+                                        {{3, 2, 2, 0}, kMass3D},
+                                        {{3, 1, 4, 0}, kNormalFlux3D, true}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];

@@ -286,6 +286,7 @@ def mf_diag_rhs(mesh, kid, R=1, dirichlet_vals=None, kparams=None, time=0.0, dia
 KERNEL_ADIABATIC2D = 5
 KERNEL_ADIABATIC3D = 6
 KERNEL_ROBIN3D = 7
+KERNEL_NORMALFLUX3D = 9
 RESIDUAL_DIFFUSION3D_ERROR = 0
 RESIDUAL_LINEAR2D_ERROR = 1
 RESIDUAL_LINEAR3D_ERROR = 2

@@ -281,3 +281,45 @@ def test_deterministic_mode_with_boundary_terms():
     wd[mask != 0] = 1.0
     wr[mask != 0] = 0.0
     assert rel_err(drs[0][0].cpu().numpy(), wd) < 1e-12 and rel_err(drs[0][1].cpu().numpy().T, wr) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ne", [(3, 3, 3), (4, 3, 1)])
+def test_deterministic_mode_with_derivative_boundary_kernel(ne):
+    """A boundary kernel that fills A1..A3 scatter-adds over EVERY node of its element (the normal derivative couples all of
+    them), so two sides may share a launch only if their elements share no node.  All six cube sides, and a mesh one element
+    thick (every element carries two to five sides): applies and diag / rhs bitwise equal run to run and equal to the oracle."""
+    import torch
+    import oracle_lib as O
+    from helpers import oracle_mesh, rel_err
+    from l3ster_amd import system
+    torch.cuda.set_device(0)
+    p, U, kp = 2, 4, [1.5, 0.4, 0.3]
+    part = system.CubePartition(ne, p, perturb=0.1)
+    mask = np.zeros(part.n_local_nodes * U, dtype=np.uint8)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_deterministic(True)
+    mesh = system.DeviceMesh(ctx, part, U, mask)
+    fe, fs = part.boundary_sides([0, 1, 2, 3, 4, 5])
+    term = system.BoundaryTerm(mesh, system.KERNEL_NORMALFLUX3D, fe, fs, kernel_params=kp)
+    x = system.synthetic_vector_torch(part.node_grid_id, U, "cuda", seed=5)
+    ys, drs = [], []
+    for _ in range(4):
+        y = torch.full_like(x, 0.125)
+        term.apply(x, y, alpha=0.75)
+        diag = torch.zeros(mask.size, dtype=torch.float64, device="cuda")
+        rhs = torch.zeros((1, mask.size), dtype=torch.float64, device="cuda")
+        term.diag_rhs(diag, rhs)
+        ys.append(y)
+        drs.append((diag, rhs))
+    torch.cuda.synchronize()
+    for k in (1, 2, 3):
+        assert torch.equal(ys[0], ys[k]) and torch.equal(drs[0][0], drs[k][0]) and torch.equal(drs[0][1], drs[k][1])
+    om = oracle_mesh(part, p + 1, U, np.arange(U), mask)
+    xh = x.cpu().numpy()
+    want = np.full((xh.shape[1], 1), 0.125, order="F")
+    O.bnd_apply(om, O.KERNEL_NORMALFLUX3D, fe, fs, np.asfortranarray(xh.T), want, alpha=0.75, kparams=kp)
+    assert rel_err(ys[0].cpu().numpy().T, want) < 1e-12
+    wd, wr = np.zeros(mask.size), np.zeros((mask.size, 1), order="F")
+    O.bnd_diag_rhs(om, O.KERNEL_NORMALFLUX3D, fe, fs, wd, wr, kparams=kp)
+    assert rel_err(drs[0][0].cpu().numpy(), wd) < 1e-12 and rel_err(drs[0][1].cpu().numpy().T, wr) < 1e-11
