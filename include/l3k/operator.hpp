@@ -137,6 +137,26 @@ private:
     int       m_dpn{};
 };
 
+// The mailboxes of the in-process transport: the ranks are threads of this process, each with its own Context (one GPU or
+// several); must outlive the halos built on its tables
+class InprocGroup
+{
+public:
+    explicit InprocGroup(int world) { check(l3k_inproc_group_create(world, &m_group)); }
+    InprocGroup(const InprocGroup&)            = delete;
+    InprocGroup& operator=(const InprocGroup&) = delete;
+    ~InprocGroup() { l3k_inproc_group_destroy(m_group); }
+    l3k_halo_transport transport(int rank) const
+    {
+        l3k_halo_transport t{};
+        check(l3k_inproc_transport(m_group, rank, &t));
+        return t;
+    }
+
+private:
+    l3k_inproc_group* m_group{};
+};
+
 // One rank's ghost exchange (ImportExportContext + Import / Export, comm/ImportExport.hpp:29-72,130-215) carried by RCCL
 // inside the library.  uniqueId(): 128 bytes drawn by one rank and handed to the others by the host's own means (the
 // reference has MPI_Bcast); the constructor is collective over the `world` ranks.
@@ -154,6 +174,14 @@ public:
         const auto& v = mesh.view();
         check(l3k_halo_create(ctx.get(), unique_id.data(), rank, world, dofs_per_node, v.n_nbrs, v.nbr_rank, v.send_offsets,
                               v.send_nodes, v.ghost_offsets, &m_halo));
+    }
+    // With a transport table instead of RCCL: the host's own (e.g. MPI on device pointers), or the library's in-process
+    // transport for the threads of one process (InprocGroup below).  Not collective.
+    Halo(Context& ctx, const CubeMesh& mesh, int dofs_per_node, const l3k_halo_transport& transport, int rank, int world)
+    {
+        const auto& v = mesh.view();
+        check(l3k_halo_create_transport(ctx.get(), &transport, rank, world, dofs_per_node, v.n_nbrs, v.nbr_rank, v.send_offsets,
+                                        v.send_nodes, v.ghost_offsets, &m_halo));
     }
     Halo(const Halo&)            = delete;
     Halo& operator=(const Halo&) = delete;

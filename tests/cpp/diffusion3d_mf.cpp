@@ -11,7 +11,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <map>
 #include <random>
+#include <thread>
 #include <vector>
 
 #define HIP_CHECK(x)                                                                                                   \
@@ -261,6 +263,70 @@ int main()
             same = same && a1[i] == a2[i], e2 += (a1[i] - y[i]) * (a1[i] - y[i]);
         std::printf("deterministic mode: two applies bitwise %s, vs atomic mode %.3e\n", same ? "equal" : "DIFFERENT", std::sqrt(e2 / nrm));
         failures += !(same && std::sqrt(e2 / nrm) < 1e-13);
+    }
+    { // two ranks as two threads of this process (each its own Context and stream), the exchange through the library's
+      // in-process transport (l3k::InprocGroup): l3k_mf_apply_dist of both ranks equals the one-rank apply of the whole mesh
+        constexpr int         p = 2, U = 4, world = 2;
+        const int             unknown0[] = {0};
+        l3k::CubeMesh         whole{{4, 2, 2}, p, {1, 1, 1}, 0, 0.1};
+        const auto            wmask = whole.dirichletMask(U, unknown0);
+        l3k::DeviceMesh       wmesh{ctx, whole, U, wmask.data()};
+        l3k::MatrixFreeSystem wsys{wmesh, L3K_KERNEL_DIFFUSION3D, params};
+        const auto&           wv = whole.view();
+        const size_t          nw = size_t(wmesh.nOwnedDofs());
+        const auto            value_of = [](int64_t grid_id, int u) { return std::sin(0.37 * double(grid_id) + u); };
+        std::vector< double > xw(nw);
+        for (size_t i = 0; i < nw; ++i)
+            xw[i] = value_of(wv.node_grid_id[i / U], int(i % U));
+        DevVec dxw{nw}, dyw{nw};
+        dxw.up(xw);
+        wsys.apply(dxw.p, nw, dyw.p, nw, 1, 1.25, 0.);
+        ctx.synchronize();
+        const auto                    yw = dyw.down();
+        std::map< int64_t, size_t >   row_of;
+        for (int64_t i = 0; i < wv.n_owned_nodes; ++i)
+            row_of[wv.node_grid_id[i]] = size_t(i);
+        l3k::InprocGroup      group{world};
+        std::vector< double > err2(world, 0.), nrm2(world, 0.);
+        std::vector< int >    bad(world, 0);
+        const auto            body = [&](int rank) {
+            try
+            {
+                l3k::Context          rctx{0};
+                l3k::CubeMesh         mesh{{4, 2, 2}, p, {2, 1, 1}, rank, 0.1};
+                const auto            mask = mesh.dirichletMask(U, unknown0);
+                l3k::DeviceMesh       dmesh{rctx, mesh, U, mask.data()};
+                l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params};
+                l3k::Halo             halo{rctx, mesh, U, group.transport(rank), rank, world};
+                const auto&           v = mesh.view();
+                const size_t          n = size_t(dmesh.nOwnedDofs());
+                std::vector< double > x(n);
+                for (size_t i = 0; i < n; ++i)
+                    x[i] = value_of(v.node_grid_id[i / U], int(i % U));
+                DevVec dx{n}, dy{n};
+                dx.up(x);
+                for (int rep = 0; rep < 3; ++rep)
+                    sys.apply(halo, dx.p, n, dy.p, n, 1, 1.25, 0.);
+                rctx.synchronize();
+                const auto y = dy.down();
+                for (size_t i = 0; i < n; ++i)
+                {
+                    const double ref = yw[row_of.at(v.node_grid_id[i / U]) * U + i % U];
+                    err2[rank] += (y[i] - ref) * (y[i] - ref), nrm2[rank] += ref * ref;
+                }
+            }
+            catch (const std::exception& e)
+            {
+                std::printf("rank %d: %s\n", rank, e.what());
+                bad[rank] = 1;
+            }
+        };
+        std::thread t0{body, 0}, t1{body, 1};
+        t0.join();
+        t1.join();
+        const double rel = std::sqrt((err2[0] + err2[1]) / (nrm2[0] + nrm2[1]));
+        std::printf("two thread ranks, in-process transport: |dy| / |y| = %.3e\n", rel);
+        failures += bad[0] + bad[1] + !(rel < 1e-12);
     }
     try
     { // error behaviour: too many columns -> exception (algsys/MatrixFreeSystem.hpp:1035-1037)
