@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 sys.path.insert(0, ROOT)
 import bench as bench_module  # noqa: E402  (kernel_source_hash: the traffic is keyed to the kernel sources it was measured on)
 
@@ -85,5 +85,73 @@ if acc:
                       f"{m.get('SQ_INSTS_SALU', 0) / 262144:.0f}, SMEM {m.get('SQ_INSTS_SMEM', 0) / 262144:.0f}\n")
         for k in sorted(m):
             out.write(f"{k:28s} n={len(acc[k])} mean={m[k]:.4g}\n")
+
+
+# ---- round 3: counters of the order-4 instance, memory-side requests, stored assembly, config 5
+def is_p4(name):
+    return "sumfactFastKernel" in name and "Diffusion3D, 4, 5" in name
+
+
+def counters_of(dirs, pred):
+    acc = {}
+    for d in dirs:
+        for f in glob.glob(os.path.join(SRC, d, f"{d}_counter_collection.csv")):
+            for row in csv.DictReader(open(f)):
+                if pred(row["Kernel_Name"]):
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def write_counters(path, header, m, n, n_elems):
+    with open(path, "w") as out:
+        out.write(header)
+        cyc = m.get("SQ_BUSY_CU_CYCLES", 0.0) / 256
+        if cyc:
+            out.write(f"#   cycles per launch (SQ_BUSY_CU_CYCLES / 256 CUs)              = {cyc:.4g}\n")
+            if "SQ_ACTIVE_INST_VALU" in m:
+                out.write(f"#   VALU busy = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles)        = {100 * 4 * m['SQ_ACTIVE_INST_VALU'] / (1024 * cyc):.1f} %\n")
+            if "SQ_WAVE_CYCLES" in m:
+                out.write(f"#   resident waves per CU = 4*SQ_WAVE_CYCLES / (256 * cycles)        = {4 * m['SQ_WAVE_CYCLES'] / (256 * cyc):.2f}\n")
+            if "SQ_LDS_IDX_ACTIVE" in m:
+                out.write(f"#   LDS pipe active = SQ_LDS_IDX_ACTIVE / (256 * cycles)             = {100 * m['SQ_LDS_IDX_ACTIVE'] / (256 * cyc):.1f} %, "
+                          f"of which bank conflicts {100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / m['SQ_LDS_IDX_ACTIVE']:.1f} %\n")
+        if "SQ_INSTS_VALU" in m and n_elems:
+            out.write(f"#   instructions per element: VALU {m['SQ_INSTS_VALU'] / n_elems:.0f}, LDS {m.get('SQ_INSTS_LDS', 0) / n_elems:.0f}, SALU "
+                      f"{m.get('SQ_INSTS_SALU', 0) / n_elems:.0f}, SMEM {m.get('SQ_INSTS_SMEM', 0) / n_elems:.0f}, vector memory "
+                      f"{(m.get('SQ_INSTS_VMEM_WR', 0) + m.get('SQ_INSTS_VMEM_RD', 0)) / n_elems:.1f}\n")
+        if "TCC_EA0_WRREQ" in m and n_elems:
+            out.write(f"#   memory-side requests per element: write requests {m['TCC_EA0_WRREQ'] / n_elems:.1f} (64-byte ones "
+                      f"{m.get('TCC_EA0_WRREQ_64B', 0) / n_elems:.1f}), of them atomics to DRAM {m.get('TCC_EA0_WRREQ_ATOMIC_DRAM', 0) / n_elems:.1f}; "
+                      f"read requests {m.get('TCC_EA0_RDREQ', 0) / n_elems:.1f}\n")
+        for k in sorted(m):
+            out.write(f"{k:28s} n={n[k]} mean={m[k]:.4g}\n")
+
+
+if os.path.isdir(os.path.join(SRC, "o4_1")):
+    m4, n4 = counters_of(["o4_1", "o4_2", "o4_3"], is_p4)
+    write_counters(os.path.join(DST, f"{tag}_pmc_fast_kernel_order4.txt"),
+                   "# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --order 4 --steps 3 --warmup 1 --no-cpu-baseline (three passes: two SQ sets, one TCC set),\n"
+                   "# sumfactFastKernel<Diffusion3D,4,5>, 64^3 elements (two per wave), mean per launch, chip-wide sums\n", m4, n4, 262144)
+if os.path.isdir(os.path.join(SRC, "o6_tcc")):
+    m6, n6 = counters_of(["o6_tcc"], is_p6)
+    write_counters(os.path.join(DST, f"{tag}_tcc_fast_kernel_64cubed.txt"),
+                   "# rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_WRREQ_ATOMIC_DRAM TCC_EA0_RDREQ --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline,\n"
+                   "# sumfactFastKernel<Diffusion3D,6,7>, 64^3 elements, mean per launch, chip-wide sums\n", m6, n6, 262144)
+if os.path.isdir(os.path.join(SRC, "asm_tcc")):
+    ma, na = counters_of(["asm_tcc", "asm_write"], lambda name: "assembleSumfactKernel" in name)
+    with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
+        out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE> --kernel-trace -- python tools/bench_assembly.py --order 6 --store --batch 64: assembleSumfactKernel<Diffusion3D,6,7>\n"
+                  "# writing 64 element matrices of 1372 x 1372 doubles (15.06 MB each, 963.7 MB per launch) row-major; mean per launch\n")
+        alg = 64 * 1372 * 1372 * 8
+        if "WRITE_SIZE" in ma:
+            out.write(f"#   WRITE_SIZE = {ma['WRITE_SIZE'] * 1024 / 1e6:.1f} MB per launch vs {alg / 1e6:.1f} MB algorithmic = x{ma['WRITE_SIZE'] * 1024 / alg:.2f}\n")
+        if "TCC_EA0_WRREQ" in ma:
+            out.write(f"#   write requests to memory: {ma['TCC_EA0_WRREQ']:.4g} per launch = {ma['TCC_EA0_WRREQ'] * 64 / alg:.2f} x (algorithmic bytes / 64); "
+                      f"64-byte ones: {ma.get('TCC_EA0_WRREQ_64B', 0):.4g} ({100 * ma.get('TCC_EA0_WRREQ_64B', 0) / ma['TCC_EA0_WRREQ']:.0f} %)\n")
+        for k in sorted(ma):
+            out.write(f"{k:28s} n={na[k]} mean={ma[k]:.4g}\n")
+if os.path.exists(os.path.join(SRC, "config5.json")):
+    with open(os.path.join(DST, f"{tag}_config5_pcg.jsonl"), "a") as out:
+        out.write(json.dumps(last_json_line(os.path.join(SRC, "config5.json"))) + "\n")
 print(json.dumps({"value": bench["value"], "kernel_ms": bench["roofline"]["kernel_ms"], "frac": bench["roofline"]["frac"],
                   "traffic_GB": traffic / 1e9}))
