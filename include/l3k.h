@@ -309,6 +309,23 @@ int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, do
 int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F,
                           const int64_t* d_row_ptr, const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr,
                           int skip_dirichlet, int64_t* n_missing);
+/* assembleGlobalSystem (algsys/AssembleGlobalSystem.hpp:20-53: for every element assembleLocalSystem, then scatterLocalSystem)
+ * for the elements [first, first+count) in ONE call: the library forms sub-batches of element systems in a workspace of its
+ * own (workspace_bytes in total, 0 = 1 GiB; two halves) on the context's stream while the previous sub-batch is summed into
+ * d_values / d_rhs on a second stream -- the element matrices never leave the device and are never seen by the host.  Same
+ * graph, rhs, skip_dirichlet and n_missing semantics as l3k_assembled_scatter; d_rhs may be NULL.  Returns when the work is
+ * complete (it reads back the degenerate-element flag: error -2, "Encountered degenerate element", AssembleLocalSystem.hpp:249). */
+/* K_e of the elements [first, first+count) in the TILED layout that l3k_assemble_global keeps between its two kernels, for
+ * consumers that do not need the reference's row-major matrix: per element the U x U blocks K[(b,u),(b',u')] with the nodes
+ * b = bx + n(by + n bz), b' = bx' + n(by' + n bz') (n = order + 1) stored as [u][u'][bx'][bz][bx][by][by'][bz'], bz' fastest --
+ * Nd^2 doubles as in the row-major layout, every entry present (no mirroring left to the reader).  A wave of the assembly
+ * kernel writes 512 contiguous bytes per store (the row-major stores are 8-byte pieces at a stride of 8U bytes, measured
+ * x3.9 write traffic), a reader finds a matrix row in 4n runs of n^2 doubles.  Shapes without the sum-factorised assembly
+ * kernel (order 8) return an error. */
+int l3k_local_assemble_tiled(l3k_mf* mf, int64_t first, int64_t count, double* d_Kt);
+int l3k_assemble_global(l3k_mf* mf, int64_t first, int64_t count, const int64_t* d_row_ptr, const int32_t* d_col_ind,
+                        double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet, size_t workspace_bytes,
+                        int64_t* n_missing);
 
 /* ---- ghost exchange of a partitioned system: RCCL neighbour send / receive behind the C ABI -----------------------------
  * Stands in for comm::Import / comm::Export and their ImportExportContext (comm/ImportExport.hpp:29-72,130-215,295-372,

@@ -311,6 +311,16 @@ public:
                                     &missing));
         return missing;
     }
+    // assembleGlobalSystem (algsys/AssembleGlobalSystem.hpp:20-53) in one call: element systems formed and summed into the CSR
+    // values / right-hand sides inside the library, sub-batch by sub-batch on two streams; returns the entries outside the graph
+    int64_t assembleGlobal(int64_t first, int64_t count, const int64_t* d_row_ptr, const int32_t* d_col_ind, double* d_values,
+                           double* d_rhs, size_t ldr, bool skip_dirichlet = false, size_t workspace_bytes = 0) const
+    {
+        int64_t missing = 0;
+        check(l3k_assemble_global(m_mf, first, count, d_row_ptr, d_col_ind, d_values, d_rhs, ldr, skip_dirichlet ? 1 : 0, workspace_bytes,
+                                  &missing));
+        return missing;
+    }
     // diag(A) and rhs with Dirichlet lifting; the caller zeroes d_diag / d_rhs first (computeDiagAndRhs :921-923)
     void diagAndRhs(const double* d_dirichlet_vals, size_t ldg, double* d_diag, double* d_rhs, size_t ldr) const
     {

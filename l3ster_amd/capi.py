@@ -131,6 +131,8 @@ SIGNATURES = {
     "l3k_mf_apply_dist": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_double, C.c_double]),
     "l3k_assembled_scatter": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int,
                                         c_int64_p]),
+    "l3k_local_assemble_tiled": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp]),
+    "l3k_assemble_global": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size_t, c_int64_p]),
     "l3k_bnd_create": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, C.POINTER(AsmOpts), c_int_p, C.c_int, C.c_int64,
                                  c_int64_p, c_uint8_p, C.POINTER(_vp)]),
     "l3k_bnd_destroy": (C.c_int, [_vp]),

@@ -1362,6 +1362,216 @@ int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, do
     }
     return 0;
 }
+// K_e of the elements [first, first + count) in the TILED layout (include/l3k.h): what l3k_assemble_global keeps between its two kernels
+int l3k_local_assemble_tiled(l3k_mf* mf, int64_t first, int64_t count, double* d_Kt)
+{
+    if (!mf || !d_Kt)
+    {
+        setError("l3k_local_assemble_tiled: null argument");
+        return -1;
+    }
+    const l3k_mesh* m = mf->mesh;
+    if (first < 0 || count < 0 || first + count > m->n_elems)
+    {
+        setError("element range [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)m->n_elems);
+        return -1;
+    }
+    if (count == 0)
+        return 0;
+    const auto* inst = instanceFor(mf, mf->n_rhs);
+    if (!inst)
+        return -4;
+    if (!inst->assemble_tiled)
+    {
+        setError("l3k_local_assemble_tiled: this shape has no sum-factorised assembly kernel");
+        return -1;
+    }
+    l3k::dev::ElemArgs a;
+    if (int rc = fillArgs(mf, 2, mf->n_rhs, a))
+        return rc;
+    a.elem_begin     = first;
+    a.elem_count     = count;
+    a.elem_begin_out = 0;
+    a.K              = d_Kt;
+    a.K_tiled        = 1;
+    hipStream_t  s    = mf->ctx->stream;
+    const size_t need = inst->assemble_ws_doubles * size_t(count) + 1;
+    if (need > mf->ws_doubles)
+    {
+        if (mf->ws)
+            L3K_HIP(hipFree(mf->ws));
+        mf->ws = nullptr;
+        L3K_HIP(hipMalloc(reinterpret_cast< void** >(&mf->ws), need * sizeof(double)));
+        mf->ws_doubles = need;
+    }
+    a.workspace  = mf->ws;
+    double* flag = mf->ws + inst->assemble_ws_doubles * size_t(count);
+    L3K_HIP(hipMemsetAsync(flag, 0, sizeof(double), s));
+    if (int rc = inst->assemble(a, mf->blob.empty() ? nullptr : mf->blob.data(), s))
+        return rc;
+    double degenerate = 0.;
+    L3K_HIP(hipMemcpyAsync(&degenerate, flag, sizeof(double), hipMemcpyDeviceToHost, s));
+    L3K_HIP(hipStreamSynchronize(s));
+    if (degenerate != 0.)
+    {
+        setError("Encountered degenerate element ( |J| <= 0 )"); // algsys/AssembleLocalSystem.hpp:249
+        return -2;
+    }
+    return 0;
+}
+// assembleGlobalSystem (algsys/AssembleGlobalSystem.hpp:20-53: per element assembleLocalSystem -> scatterLocalSystem) for the
+// elements [first, first + count) as ONE call: sub-batches of element systems are formed into one of two workspace buffers on the
+// context's stream while the previous sub-batch is summed into the CSR values on a second stream -- the assembly kernels are
+// bound by the FP64 pipe, the scatter by the memory-side atomic units, so the two overlap (events order buffer reuse).
+int l3k_assemble_global(l3k_mf* mf, int64_t first, int64_t count, const int64_t* d_row_ptr, const int32_t* d_col_ind,
+                        double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet, size_t workspace_bytes, int64_t* n_missing)
+{
+    if (!mf || !d_row_ptr || !d_col_ind || !d_values)
+    {
+        setError("l3k_assemble_global: null argument");
+        return -1;
+    }
+    const l3k_mesh* m = mf->mesh;
+    if (first < 0 || count < 0 || first + count > m->n_elems)
+    {
+        setError("element range [%lld, %lld) outside [0, %lld)", (long long)first, (long long)(first + count), (long long)m->n_elems);
+        return -1;
+    }
+    const int64_t n_local_dofs = (m->n_owned_nodes + m->n_ghost_nodes) * m->dofs_per_node;
+    if (d_rhs && ldr < size_t(n_local_dofs))
+    {
+        setError("rhs leading dimension smaller than the number of local dofs");
+        return -1;
+    }
+    if (n_missing)
+        *n_missing = 0;
+    if (count == 0)
+        return 0;
+    const auto* inst = instanceFor(mf, mf->n_rhs);
+    if (!inst)
+        return -4;
+    L3K_HIP(hipSetDevice(mf->ctx->device));
+    // element matrices between the two kernels in the tiled layout where the sum-factorised assembly kernel exists (its stores
+    // coalesce, the scatter transposes a row through LDS); L3K_GLOBAL_ROW_MAJOR=1 keeps the reference's row-major layout
+    const int    tiled = inst->assemble_tiled && mf->kp.n_unknowns <= 4 && m->order <= 7 && std::getenv("L3K_GLOBAL_ROW_MAJOR") == nullptr &&
+                               std::getenv("L3K_ASSEMBLE_DENSE") == nullptr
+                           ? 1
+                           : 0;
+    const int    N1 = m->order + 1, Nd = N1 * N1 * N1 * mf->kp.n_unknowns, R = mf->n_rhs;
+    const size_t per_elem = sizeof(double) * (size_t(Nd) * Nd + size_t(Nd) * R + inst->assemble_ws_doubles);
+    if (workspace_bytes == 0)
+        workspace_bytes = size_t(1) << 30;
+    int64_t nb = int64_t(workspace_bytes / 2 / per_elem);
+    nb         = nb < 1 ? 1 : (nb > count ? count : nb);
+    // at least ~8 sub-batches per call where the batch stays large enough for full launches (the overlap needs several)
+    if (const int64_t eighth = (count + 7) / 8; nb > eighth && eighth >= 512)
+        nb = eighth;
+    while (nb * Nd > int64_t(0x7fffffff) / 64 && nb > 1) // (launch-size limits of the kernels)
+        nb /= 2;
+    const size_t kd = size_t(nb) * Nd * Nd, fd = d_rhs ? size_t(nb) * Nd * R : 0, wd = inst->assemble_ws_doubles * size_t(nb) + 1;
+    auto&        g  = mf->gasm;
+    if (g.doubles < kd + fd + wd)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            if (g.buf[k])
+                L3K_HIP(hipFree(g.buf[k]));
+            g.buf[k] = nullptr;
+        }
+        g.doubles = 0;
+        for (int k = 0; k < 2; ++k)
+            L3K_HIP(hipMalloc(reinterpret_cast< void** >(&g.buf[k]), (kd + fd + wd) * sizeof(double)));
+        g.doubles = kd + fd + wd;
+    }
+    if (!g.second)
+    {
+        L3K_HIP(hipStreamCreateWithFlags(&g.second, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k)
+        {
+            L3K_HIP(hipEventCreateWithFlags(&g.formed[k], hipEventDisableTiming));
+            L3K_HIP(hipEventCreateWithFlags(&g.consumed[k], hipEventDisableTiming));
+        }
+    }
+    struct Side
+    {
+        double *   K, *F, *ws;
+        hipEvent_t formed, consumed;
+    } side[2];
+    for (int k = 0; k < 2; ++k)
+        side[k] = Side{g.buf[k], g.buf[k] + kd, g.buf[k] + kd + fd, g.formed[k], g.consumed[k]};
+    struct
+    {
+        hipStream_t s;
+    } second{g.second};
+    hipStream_t         sa      = mf->ctx->stream;
+    const void*         blob    = mf->blob.empty() ? nullptr : mf->blob.data();
+    unsigned long long* d_count = n_missing ? mf->ctx->missCounter() : nullptr;
+    if (d_count)
+        L3K_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), sa));
+    // (the flags of degenerate elements: the trailing double of each coefficient workspace, set by the kernels, never cleared here)
+    for (auto& sd : side)
+        L3K_HIP(hipMemsetAsync(sd.ws + inst->assemble_ws_doubles * size_t(nb), 0, sizeof(double), sa));
+    int64_t done  = 0;
+    int     n_sub = 0;
+    for (int i = 0; done < count; ++i, ++n_sub)
+    {
+        Side&         sd = side[i & 1];
+        const int64_t n  = count - done < nb ? count - done : nb;
+        if (i >= 2)
+            L3K_HIP(hipStreamWaitEvent(sa, sd.consumed, 0)); // the scatter of sub-batch i - 2 has read this buffer
+        l3k::dev::ElemArgs a;
+        if (int rc = fillArgs(mf, 2, mf->n_rhs, a))
+            return rc;
+        a.elem_begin     = first + done;
+        a.elem_count     = n;
+        a.elem_begin_out = 0;
+        a.K              = sd.K;
+        a.K_tiled        = tiled;
+        a.F              = d_rhs ? sd.F : nullptr;
+        a.checksum       = nullptr;
+        // (the kernels keep the degenerate-element flag behind the coefficients of THEIR elem_count elements: a short last
+        // sub-batch works in the tail of the buffer, so that the flag has one position per buffer)
+        a.workspace      = sd.ws + size_t(nb - n) * inst->assemble_ws_doubles;
+        if (int rc = inst->assemble(a, blob, sa))
+            return rc;
+        if (d_rhs)
+        {
+            L3K_HIP(hipMemsetAsync(sd.F, 0, sizeof(double) * size_t(n) * Nd * R, sa));
+            a.dirichlet      = nullptr;
+            a.elem_flags     = nullptr;
+            a.dirichlet_vals = nullptr;
+            a.diag           = nullptr;
+            a.local_out      = 1;
+            a.y              = sd.F;
+            if (int rc = inst->diag_rhs(a, blob, sa))
+                return rc;
+        }
+        L3K_HIP(hipEventRecord(sd.formed, sa));
+        L3K_HIP(hipStreamWaitEvent(second.s, sd.formed, 0));
+        if (int rc = launchAssembledScatter(mf, first + done, n, sd.K, d_rhs ? sd.F : nullptr, d_row_ptr, d_col_ind, d_values, d_rhs,
+                                            ldr, skip_dirichlet, d_count, second.s, tiled))
+            return rc;
+        L3K_HIP(hipEventRecord(sd.consumed, second.s));
+        done += n;
+    }
+    for (int k = 0; k < 2 && k < n_sub; ++k)
+        L3K_HIP(hipStreamWaitEvent(sa, side[k].consumed, 0)); // later work on the context's stream sees the finished values
+    double             flags[2] = {0., 0.};
+    unsigned long long h        = 0;
+    for (int k = 0; k < 2; ++k)
+        L3K_HIP(hipMemcpyAsync(&flags[k], side[k].ws + inst->assemble_ws_doubles * size_t(nb), sizeof(double), hipMemcpyDeviceToHost, sa));
+    if (d_count)
+        L3K_HIP(hipMemcpyAsync(&h, d_count, sizeof h, hipMemcpyDeviceToHost, sa));
+    L3K_HIP(hipStreamSynchronize(sa));
+    if (n_missing)
+        *n_missing = int64_t(h);
+    if (flags[0] != 0. || flags[1] != 0.)
+    {
+        setError("Encountered degenerate element ( |J| <= 0 )"); // algsys/AssembleLocalSystem.hpp:249
+        return -2;
+    }
+    return 0;
+}
 // ------------------------------------------------------------------------------------------------ boundary terms
 int l3k_bnd_create(l3k_ctx* ctx, l3k_mesh* mesh, int kernel_id, const void* kparam_blob, size_t kparam_bytes,
                    const l3k_asmopts* opts, const int* field_inds, int n_rhs, int64_t n_faces, const int64_t* face_elem,

@@ -147,7 +147,179 @@ __global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a
     if (missing && a.n_missing)
         atomicAdd(a.n_missing, static_cast< unsigned long long >(missing));
 }
+// The scatter for element matrices in the TILED layout of the assembly kernel (device/assemble.hpp, TILED): blocks
+// [u][u'][bx'][bz][bx][by][by'][bz'].  One wave per (element, row node b): for every row (b, u) the 4 n runs of n^2 doubles that
+// hold the row (one per (u', bx')) are read -- consecutive lanes, consecutive addresses -- and laid down in LDS in the row's
+// column order (b', u'), u' fastest: from there the lanes walk the row's consecutive entries exactly as assembledScatterKernel
+// does (dense atomic requests), and the CSR position of an entry is searched once, for the first live row of the node (kept
+// in LDS as an offset into the row), and re-used for the others after a check.
+template < int U, int N1 >
+__global__ __launch_bounds__(64) void assembledScatterTiledKernel(const ScatterArgs a)
+{
+    extern __shared__ double lds[];
+    constexpr int   N2 = N1 * N1, NN = N2 * N1, Nd = NN * U;
+    double* const   rowv = lds;                                      // [Nd] the row in column order
+    int32_t* const  relv = reinterpret_cast< int32_t* >(lds + Nd);  // [Nd] position of the entry's column in the node's rows
+    const int64_t   e    = blockIdx.x / NN;
+    const int       b    = int(blockIdx.x - e * NN);
+    const uint32_t* en   = a.elem_nodes + (a.first + e) * NN;
+    const int       lane = threadIdx.x;
+    const int64_t   nb   = int64_t(en[b]) * a.dpn;
+    const int       bx = b % N1, by = (b / N1) % N1, bz = b / N2; // row node b = bx + N1 (by + N1 bz)
+    if (a.F && a.rhs && lane < a.n_rhs * U)
+    {
+        const int     r = lane / U, u = lane - r * U;
+        const int64_t row = nb + a.field_inds[u];
+        if (!(a.skip_dirichlet && a.dirichlet && a.dirichlet[row]))
+            unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row, a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
+    }
+    if (!a.K || !a.values)
+        return;
+    const double* Ke       = a.K + e * int64_t(Nd) * Nd;
+    const int64_t row_off  = ((int64_t(bz) * N1 + bx) * N1 + by) * N2; // + cx * NN * N2: start of the run (u', bx' = cx)
+    unsigned      missing  = 0;
+    bool          have_rel = false;
+#pragma unroll 1
+    for (int u = 0; u < U; ++u)
+    {
+        const int64_t row = nb + a.field_inds[u];
+        if (a.skip_dirichlet && a.dirichlet && a.dirichlet[row]) // (wave-uniform)
+            continue;
+        __syncthreads(); // the previous row has been consumed
+        // ---- the row's U N1 runs of N2 doubles (by', bz'; bz' fastest) -> LDS in column order (b', u'), u' fastest: entry i of
+        // the concatenated runs, the lanes over i
+        const double* Kr = Ke + int64_t(u) * U * NN * NN + row_off;
+#pragma unroll 4
+        for (int i = lane; i < Nd; i += 64)
+        {
+            const int run = i / N2, k = i - run * N2, up = run / N1, cx = run - up * N1, cy = k / N1, cz = k - cy * N1;
+            rowv[((cz * N1 + cy) * N1 + cx) * U + up] = Kr[int64_t(up) * NN * NN + int64_t(cx) * NN * N2 + k];
+        }
+        __syncthreads();
+        const int64_t rb = a.row_ptr[row], re = a.row_ptr[row + 1];
+        for (int j = lane; j < Nd; j += 64)
+        {
+            const int     bp  = j / U;
+            const int64_t col = int64_t(en[bp]) * a.dpn + a.field_inds[j - bp * U];
+            if (a.skip_dirichlet && a.dirichlet && a.dirichlet[col])
+                continue;
+            int64_t pos;
+            if (!have_rel)
+            {
+                pos     = lowerBound(a.col_ind, rb, re, col);
+                relv[j] = int32_t(pos - rb);
+            }
+            else
+            {
+                pos = rb + relv[j];
+                if (!(pos < re && a.col_ind[pos] == col))
+                    pos = lowerBound(a.col_ind, rb, re, col);
+            }
+            if (pos < re && a.col_ind[pos] == col)
+                unsafeAtomicAdd(a.values + pos, rowv[j]);
+            else
+                ++missing;
+        }
+        have_rel = true;
+    }
+    if (missing && a.n_missing)
+        atomicAdd(a.n_missing, static_cast< unsigned long long >(missing));
+}
+template < int U >
+int launchScatterTiled(const ScatterArgs& a, int N1, int64_t blocks, hipStream_t s)
+{
+    const size_t lds = size_t(a.NN) * U * (sizeof(double) + sizeof(int32_t));
+    switch (N1)
+    {
+    case 2: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 2 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 3 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 4 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 5: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 5 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 6: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 6 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 7: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 7 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((assembledScatterTiledKernel< U, 8 >), dim3(unsigned(blocks)), dim3(64), lds, s, a); break;
+    default: return 1;
+    }
+    return 0;
+}
 } // namespace
+
+// the launch of the batch scatter on `s` (shared by l3k_assembled_scatter and the pipelined l3k_assemble_global)
+int launchAssembledScatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
+                           const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet,
+                           unsigned long long* d_count, hipStream_t s, int tiled)
+{
+    const l3k_mesh* m  = mf->mesh;
+    const int       N1 = m->order + 1, NN = N1 * N1 * N1;
+    const int64_t   blocks = count * NN;
+    if (blocks > int64_t(0x7fffffff))
+    {
+        setError("batch too large: %lld element rows in one launch", (long long)blocks);
+        return -1;
+    }
+    ScatterArgs a{};
+    a.elem_nodes     = m->elem_nodes.ptr;
+    a.dirichlet      = m->dirichlet.ptr;
+    a.K              = d_K;
+    a.F              = d_F;
+    a.row_ptr        = d_row_ptr;
+    a.col_ind        = d_col_ind;
+    a.values         = d_values;
+    a.rhs            = d_rhs;
+    a.ldr            = ldr;
+    a.n_missing      = d_count;
+    a.first          = first;
+    a.count          = count;
+    a.NN             = NN;
+    a.dpn            = m->dofs_per_node;
+    a.n_rhs          = mf->n_rhs;
+    a.skip_dirichlet = skip_dirichlet;
+    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
+        a.field_inds[u] = mf->field_inds[u];
+    a.U_rt = mf->kp.n_unknowns;
+    if (tiled)
+    {
+        int rc = 1;
+        switch (mf->kp.n_unknowns)
+        {
+        case 1: rc = launchScatterTiled< 1 >(a, N1, blocks, s); break;
+        case 2: rc = launchScatterTiled< 2 >(a, N1, blocks, s); break;
+        case 3: rc = launchScatterTiled< 3 >(a, N1, blocks, s); break;
+        case 4: rc = launchScatterTiled< 4 >(a, N1, blocks, s); break;
+        default: break;
+        }
+        if (rc)
+        {
+            setError("tiled scatter: shape (order %d, %d unknowns) not instantiated", m->order, mf->kp.n_unknowns);
+            return -1;
+        }
+    }
+    else if (std::getenv("L3K_SCATTER_PER_ENTRY"))
+    {
+        const int64_t rows = count * NN * mf->kp.n_unknowns;
+        if (rows > int64_t(0x7fffffff))
+        {
+            setError("batch too large: %lld element rows in one launch", (long long)rows);
+            return -1;
+        }
+        hipLaunchKernelGGL(assembledScatterPerEntryKernel, dim3(unsigned(rows)), dim3(64), 0, s, a);
+    }
+    else
+        switch (mf->kp.n_unknowns)
+        {
+        case 1: hipLaunchKernelGGL(assembledScatterKernel< 1 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(assembledScatterKernel< 2 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(assembledScatterKernel< 3 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(assembledScatterKernel< 4 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 5: hipLaunchKernelGGL(assembledScatterKernel< 5 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(assembledScatterKernel< 6 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 7: hipLaunchKernelGGL(assembledScatterKernel< 7 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(assembledScatterKernel< 8 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
+        default: setError("l3k_assembled_scatter: %d unknowns not supported (1..8)", mf->kp.n_unknowns); return -1;
+        }
+    L3K_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" {
 int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
@@ -186,13 +358,6 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
     if (count == 0 || (!d_K && !d_F))
         return 0;
     L3K_HIP(hipSetDevice(mf->ctx->device));
-    const int     N1 = m->order + 1, NN = N1 * N1 * N1;
-    const int64_t blocks = count * NN;
-    if (blocks > int64_t(0x7fffffff))
-    {
-        setError("batch too large: %lld element rows in one launch", (long long)blocks);
-        return -1;
-    }
     hipStream_t         s       = mf->ctx->stream;
     unsigned long long* d_count = nullptr; // (a counter of the context: no allocation per call)
     if (n_missing)
@@ -200,50 +365,8 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
         d_count = mf->ctx->missCounter();
         L3K_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
     }
-    ScatterArgs a{};
-    a.elem_nodes     = m->elem_nodes.ptr;
-    a.dirichlet      = m->dirichlet.ptr;
-    a.K              = d_K;
-    a.F              = d_F;
-    a.row_ptr        = d_row_ptr;
-    a.col_ind        = d_col_ind;
-    a.values         = d_values;
-    a.rhs            = d_rhs;
-    a.ldr            = ldr;
-    a.n_missing      = d_count;
-    a.first          = first;
-    a.count          = count;
-    a.NN             = NN;
-    a.dpn            = m->dofs_per_node;
-    a.n_rhs          = mf->n_rhs;
-    a.skip_dirichlet = skip_dirichlet;
-    for (int u = 0; u < l3k::dev::max_unknowns; ++u)
-        a.field_inds[u] = mf->field_inds[u];
-    a.U_rt = mf->kp.n_unknowns;
-    if (std::getenv("L3K_SCATTER_PER_ENTRY"))
-    {
-        const int64_t rows = count * NN * mf->kp.n_unknowns;
-        if (rows > int64_t(0x7fffffff))
-        {
-            setError("batch too large: %lld element rows in one launch", (long long)rows);
-            return -1;
-        }
-        hipLaunchKernelGGL(assembledScatterPerEntryKernel, dim3(unsigned(rows)), dim3(64), 0, s, a);
-    }
-    else
-    switch (mf->kp.n_unknowns)
-    {
-    case 1: hipLaunchKernelGGL(assembledScatterKernel< 1 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(assembledScatterKernel< 2 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(assembledScatterKernel< 3 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(assembledScatterKernel< 4 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(assembledScatterKernel< 5 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 6: hipLaunchKernelGGL(assembledScatterKernel< 6 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 7: hipLaunchKernelGGL(assembledScatterKernel< 7 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(assembledScatterKernel< 8 >, dim3(unsigned(blocks)), dim3(64), 0, s, a); break;
-    default: setError("l3k_assembled_scatter: %d unknowns not supported (1..8)", mf->kp.n_unknowns); return -1;
-    }
-    L3K_HIP(hipGetLastError());
+    if (int rc = launchAssembledScatter(mf, first, count, d_K, d_F, d_row_ptr, d_col_ind, d_values, d_rhs, ldr, skip_dirichlet, d_count, s, 0))
+        return rc;
     if (n_missing)
     {
         unsigned long long h = 0;

@@ -386,7 +386,11 @@ __device__ __forceinline__ int opaqueOffset(int x)
     asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
     return y;
 }
-template < typename K, int P, int NQ >
+// TILED: all U x U blocks (no symmetry: a few FP64 instructions for a layout that a wave can WRITE in 512-byte pieces and a row
+// reader can READ in runs of n^2 doubles), stored as [u][u'][bx'][bz][bx][by][by'][bz'] -- row node b = (bx, by, bz), column node
+// b' = (bx', by', bz').  In the row-major layout of the reference every 64-byte line of K_e collects its 8 entries from four
+// workgroups and two iterations: measured write traffic 3.9 x the matrix (profiles/r03_tcc_assembly_stored.txt).
+template < typename K, int P, int NQ, bool TILED = false >
 __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
                                                                                        int64_t elem0, int xcd_group)
 {
@@ -410,7 +414,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     // workgroups of ONE element have the same index modulo 8, i.e. sit on one XCD and share its L2 -- in stored mode every
     // 64-byte line of K_e receives its 8 entries from 4 pair-workgroups (the unknown u' is the fastest index of a row), so
     // they should at least meet in one L2.  Otherwise blockIdx = pair + NP * element.
-    constexpr int NP = U * (U + 1) / 2;
+    constexpr int NP = TILED ? U * U : U * (U + 1) / 2;
     int64_t       el;
     int           rem;
     if (xcd_group)
@@ -427,12 +431,18 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
         el  = blockIdx.x / NP;
         rem = int(blockIdx.x - el * NP);
     }
-    int u = 0; // unknown pair of this workgroup: u' <= u
-    while (rem > u)
+    int u = 0; // unknown pair of this workgroup: u' <= u (TILED: every pair)
+    if constexpr (TILED)
     {
-        rem -= u + 1;
-        ++u;
+        u   = rem / U;
+        rem = rem - u * U;
     }
+    else
+        while (rem > u)
+        {
+            rem -= u + 1;
+            ++u;
+        }
     const int up = rem;
 
     // ---- product tables and G
@@ -474,7 +484,9 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
 
     // this thread's row (bx = pp, by, by') and its rows of the y product tables
     const bool has_row = tid < ROWS;
-    const int  row = has_row ? tid : 0, pp = row / N2, bb = row - pp * N2, by = bb % N1, byp = bb / N1;
+    // (TILED: by' runs fastest over the threads, so that consecutive threads write consecutive column nodes of one row node)
+    const int  row = has_row ? tid : 0, pp = row / N2, bbt = row - pp * N2, by = TILED ? bbt / N1 : bbt % N1, byp = TILED ? bbt % N1 : bbt / N1;
+    const int  bb  = by + N1 * byp; // pair index of the y product tables
 
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
@@ -570,7 +582,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
             // W[bz][s'][qz] = sum_s B[s + 2 s'][qz] T_s[bz][qz]: 4 nq n + 2 nq n^2 = 882 FMAs per row instead of 4 nq n^2 = 1 372,
             // and every scalar operand of the second step (the 1-D tables through scalar loads) serves a block of ZB values of bz
             // instead of one entry -- the first form waited for its scalar loads (56 scalar registers per column)
-            const bool    diag_block = u == up;
+            const bool    diag_block = !TILED && u == up;
             constexpr int ZB = 2; // values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills)
             const __attribute__((address_space(4))) double* const tIz =
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
@@ -613,15 +625,22 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                             const int    bz = b0 + bi;
                             const double m  = Mz[bi][bzp];
                             const int  b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
-                            const bool skip = u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
+                            const bool skip = !TILED && u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
                             const int  gi = b * U + u, gj = bp * U + up;
-                            if (Kel && !skip)
+                            if constexpr (TILED)
+                            {
+                                constexpr int64_t NNc = int64_t(N1) * N2;
+                                Kel[(u * U + up) * NNc * NNc + ((int64_t(bxp) * N1 + bz) * ROWS + row) * N1 + bzp] = m;
+                            }
+                            else if (Kel && !skip)
                             {
                                 Kel[int64_t(gi) * ND + gj] = m;
                                 if (gi != gj)
                                     Kel[int64_t(gj) * ND + gi] = m;
                             }
-                            if constexpr (wgt_const)
+                            if constexpr (TILED)
+                                ;
+                            else if constexpr (wgt_const)
                             {
                                 s_lo += bz > bzp ? m : 0.;
                                 s_eq += bz == bzp ? m : 0.;
@@ -631,7 +650,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                                 csum += (gi != gj ? 2. : 1.) * double(1 + (gi * 31 + gj * 17) % 7) * m;
                         }
             }
-            if constexpr (wgt_const)
+            if constexpr (!TILED && wgt_const)
             {
                 // weight of this (row, column-x) pair; entries of off-diagonal blocks stand for themselves and their mirror
                 // image, in diagonal blocks those with b' < b do, b' == b counts once, b' > b is the mirror image of a counted one
@@ -695,7 +714,9 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                       hipFuncSetAttribute(reinterpret_cast< const void* >(kg), hipFuncAttributeMaxDynamicSharedMemorySize, int(C::lds)) == hipSuccess;
             if constexpr (S::feasible)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess;
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, true >),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess;
             if (!ok)
             {
                 setError("hipFuncSetAttribute failed for the assembly kernels");
@@ -707,12 +728,17 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     double* cbuf = a.workspace; // coeffStride * nq^3 doubles per element, + 1 flag
     hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
     // the sum-factorised kernel unless it does not fit or L3K_ASSEMBLE_DENSE=1 asks for the dense MFMA product (cross-check)
-    const bool dense = !S::feasible || std::getenv("L3K_ASSEMBLE_DENSE") != nullptr;
+    const bool dense = !S::feasible || (std::getenv("L3K_ASSEMBLE_DENSE") != nullptr && !a.K_tiled);
+    if (a.K_tiled && (!S::feasible || !a.K))
+    {
+        setError("the tiled layout of the element matrices needs the sum-factorised assembly kernel (this shape has none)");
+        return -1;
+    }
     if constexpr (S::feasible)
         if (!dense)
         {
-            auto ks = assembleSumfactKernel< K, P, NQ >;
-            constexpr int NP        = U * (U + 1) / 2;
+            auto          ks        = a.K_tiled ? assembleSumfactKernel< K, P, NQ, true > : assembleSumfactKernel< K, P, NQ >;
+            const int     NP        = a.K_tiled ? U * U : U * (U + 1) / 2;
             const int     xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
             const int64_t n_blocks  = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
             if (n_blocks > int64_t(0x7fffffff))

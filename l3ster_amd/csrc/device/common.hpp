@@ -85,6 +85,7 @@ struct ElemArgs
     double*       diag_g;
     // local assembly
     double* K;         // [count][Nd][Nd] row-major or nullptr
+    int     K_tiled;   // K in the tiled layout of l3k_local_assemble_tiled (all U x U blocks, no mirroring) instead of row-major
     double* F;         // [count][Nd][R] column-major per element (RHS-mode kernel with local_out)
     double* checksum;  // [count] or nullptr
     double* workspace; // per-QP coefficients of the batch + 1 trailing flag (degenerate element)
@@ -115,6 +116,7 @@ struct Instance
     LaunchFn assemble;
     size_t   assemble_ws_doubles; // workspace doubles per element for `assemble`
     LaunchFn apply_cols = nullptr; // ncols == 1 instances: applies a.n_cols columns in one pass over the elements, or nullptr
+    bool     assemble_tiled = false; // `assemble` can write the tiled layout (ElemArgs::K_tiled): the sum-factorised kernel fits
 };
 
 // boundary equation kernel on element sides (device/boundary.hpp)

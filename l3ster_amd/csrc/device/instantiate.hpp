@@ -100,7 +100,8 @@ constexpr LaunchFn selectApply()
                                           &::l3k::dev::launchDiagRhs< T, P, NQ, R >,                               \
                                           &::l3k::dev::launchAssemble< T, P, NQ >,                                 \
                                           ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >(),               \
-                                          ::l3k::dev::selectApplyCols< T, P, NQ, R >()});                            \
+                                          ::l3k::dev::selectApplyCols< T, P, NQ, R >(),                              \
+                                          ::l3k::dev::SfAsmCfg< P, NQ >::feasible});                                 \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
     }

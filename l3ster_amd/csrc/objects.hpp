@@ -171,10 +171,30 @@ struct l3k_mf
     int                 energy_expected = 0;     // ... of how many non-empty ones: equal = fused, else the caller takes a dot product
     double*             ws = nullptr; // LocalAssembly workspace (grown on demand)
     size_t              ws_doubles = 0;
+    // l3k_assemble_global: two halves of element-system buffers, a second stream and the events that order their reuse; kept
+    // across calls (allocating gigabytes per call cost more than the pipeline saved)
+    struct GlobalAsm
+    {
+        double*     buf[2]      = {nullptr, nullptr};
+        size_t      doubles     = 0; // per half
+        hipStream_t second      = nullptr;
+        hipEvent_t  formed[2]   = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    } gasm;
     ~l3k_mf()
     {
         if (ws)
             (void)hipFree(ws);
+        for (int k = 0; k < 2; ++k)
+        {
+            if (gasm.buf[k])
+                (void)hipFree(gasm.buf[k]);
+            if (gasm.formed[k])
+                (void)hipEventDestroy(gasm.formed[k]);
+            if (gasm.consumed[k])
+                (void)hipEventDestroy(gasm.consumed[k]);
+        }
+        if (gasm.second)
+            (void)hipStreamDestroy(gasm.second);
     }
 };
 
@@ -214,4 +234,8 @@ struct KernelMeta
 const KernelMeta* findKernel(int id);
 const KernelMeta* findResidual(int id);
 } // namespace l3k::api
+// api_assembled.hip: the batch scatter of element systems into CSR values on a given stream
+int launchAssembledScatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
+                           const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet,
+                           unsigned long long* d_count, hipStream_t s, int tiled);
 #endif

@@ -572,6 +572,29 @@ class MatrixFreeSystem:
                                                 int(skip_dirichlet), C.byref(missing)))
         return missing.value
 
+    def local_assemble_tiled(self, first=0, count=None):
+        """K_e of the elements [first, first + count) in the tiled layout of l3k_local_assemble_tiled: a tensor
+        [count, U, U, n, n, n, n, n, n] indexed [e, u, u', bx', bz, bx, by, by', bz']."""
+        import torch
+        count = self.mesh.part.n_elems - first if count is None else count
+        n, U = self.mesh.part.order + 1, self.info["n_unknowns"]
+        Kt = torch.empty((count, U, U, n, n, n, n, n, n), dtype=torch.float64, device="cuda")
+        check(capi.load().l3k_local_assemble_tiled(self._h, first, count, _ptr(Kt)))
+        return Kt
+
+    def assemble_global(self, row_ptr, col_ind, values, rhs=None, first=0, count=None, skip_dirichlet=False, workspace_bytes=0):
+        """assembleGlobalSystem for the elements [first, first + count) (algsys/AssembleGlobalSystem.hpp:20-53): element systems
+        formed and summed into `values` (over the CSR graph row_ptr int64 / col_ind int32) and `rhs` [n_rhs, n_local_dofs] inside
+        the library, assembly and scatter of consecutive sub-batches overlapped on two streams.  Returns the number of entries
+        outside the graph."""
+        import ctypes as C
+        count = self.mesh.part.n_elems - first if count is None else count
+        missing = C.c_int64(0)
+        check(capi.load().l3k_assemble_global(self._h, first, count, _ptr(row_ptr), _ptr(col_ind), _ptr(values), _ptr(rhs),
+                                              0 if rhs is None else rhs.stride(0) if rhs.dim() == 2 else rhs.numel(),
+                                              int(skip_dirichlet), workspace_bytes, C.byref(missing)))
+        return missing.value
+
     def new_ghost_buffer(self, ncols, like):
         import torch
         return torch.zeros((ncols, max(self.mesh.n_ghost_dofs, 1)), dtype=torch.float64, device=like.device)

@@ -109,6 +109,26 @@ def test_local_assembly_order6_vs_oracle_entrywise(ctx, dense, monkeypatch):
             assert np.array_equal(K[e], K[e].T)
 
 
+@pytest.mark.parametrize("kid,ne,p,vo,kpar", [(system.KERNEL_DIFFUSION3D, 2, 2, 1, [0.7, 1.3]), (system.KERNEL_DIFFUSION3D, (2, 1, 1), 3, 2, [1.0, 0.5]),
+                                              (system.KERNEL_MASS3D, 2, 3, 2, None), (system.KERNEL_DIFFUSION3D, (2, 1, 1), 4, 1, [1.0, 1.0]),
+                                              (system.KERNEL_DIFFUSION3D, 1, 6, 1, [0.7, 1.3])])
+def test_tiled_layout_is_the_row_major_matrix(ctx, kid, ne, p, vo, kpar):
+    """l3k_local_assemble_tiled (every U x U block, stored [u][u'][bx'][bz][bx][by][by'][bz']: the layout l3k_assemble_global keeps
+    between its kernels) holds the entries of the row-major K_e of l3k_local_assemble -- which the tests above pin against the
+    oracle -- including the mirrored halves, which the tiled kernel computes instead of copying."""
+    U = system.kernel_info(kid)["n_unknowns"]
+    part = system.CubePartition(ne, p, perturb=0.15)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U), kid, kpar, asm_opts=(vo, 0, 0))
+    K, _, _ = mf.local_assemble(want_F=False)
+    Kt = mf.local_assemble_tiled()
+    torch.cuda.synchronize()
+    n = p + 1
+    # [e, u, u', bx', bz, bx, by, by', bz'] -> [e, (bz, by, bx, u), (bz', by', bx', u')]
+    K2 = Kt.permute(0, 4, 6, 5, 1, 8, 7, 3, 2).reshape(part.n_elems, n ** 3 * U, n ** 3 * U)
+    scale = K.abs().amax()
+    assert float((K2 - K).abs().amax()) < 1e-13 * float(scale)
+
+
 def test_degenerate_element_is_an_error(ctx):
     bad = HEX.copy()
     bad[[0, 1]] = bad[[1, 0]]
@@ -202,17 +222,19 @@ def _csr_graph(part, dpn, field_inds):
     return G.indptr.astype(np.int64), G.indices.astype(np.int32), n
 
 
-@pytest.mark.parametrize("per_entry", [False, True])
+@pytest.mark.parametrize("mode", ["node_rows", "per_entry", "global"])
 @pytest.mark.parametrize("kid,p,vo,R,kpar", [(system.KERNEL_DIFFUSION3D, 2, 1, 2, [0.7, 1.3]), (system.KERNEL_MASS3D, 3, 2, 1, None),
                                              (system.KERNEL_DIFFUSION3D, 4, 1, 1, [1.0, 1.0])])
-def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, per_entry, monkeypatch):
+def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, mode, monkeypatch):
     """a20, scatterLocalSystem + assembleGlobalSystem (algsys/ScatterLocalSystem.hpp:24-54, AssembleGlobalSystem.hpp:20-53)
     on the device: local systems of a 3^3 (2^3 at order 4) distorted mesh from l3k_local_assemble summed into the caller's
     CSR values and the global right-hand sides, in two batches; against the oracle's element systems added into a dense
     global matrix on the host.  Then with skip_dirichlet: the assembled operator equals the matrix-free apply."""
     import scipy.sparse as sp
-    # default: one search per (row node, column node) pair, the U x U block reuses it; L3K_SCATTER_PER_ENTRY=1: a search per entry
-    if per_entry:
+    # node_rows (default): one wave per (element, row node), one search per entry shared by the node's U rows; per_entry
+    # (L3K_SCATTER_PER_ENTRY=1): the round-2 kernel, a search per entry; global: l3k_assemble_global, the whole pipeline inside
+    # the library (sub-batches of element systems formed on one stream and scattered on another)
+    if mode == "per_entry":
         monkeypatch.setenv("L3K_SCATTER_PER_ENTRY", "1")
     else:
         monkeypatch.delenv("L3K_SCATTER_PER_ENTRY", raising=False)
@@ -231,9 +253,15 @@ def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, per_entry, 
         vals = torch.zeros(len(col_ind), dtype=torch.float64, device="cuda")
         rhs = torch.zeros((R, n), dtype=torch.float64, device="cuda")
         half = part.n_elems // 2
-        for first, count in ((0, half), (half, part.n_elems - half)):
-            K, Fe, _ = mf.local_assemble(first, count)
-            assert mf.assembled_scatter(K, Fe, RP, CI, vals, rhs, first=first, skip_dirichlet=skip) == 0
+        if mode == "global":
+            Nd = (p + 1) ** 3 * U
+            ws = 2 * 3 * 8 * (Nd * Nd + Nd * R + 8 * (p + 2) ** 3 * 128)  # room for about three elements per half: many sub-batches
+            assert mf.assemble_global(RP, CI, vals, rhs, first=0, count=half, skip_dirichlet=skip, workspace_bytes=ws) == 0
+            assert mf.assemble_global(RP, CI, vals, rhs, first=half, skip_dirichlet=skip) == 0
+        else:
+            for first, count in ((0, half), (half, part.n_elems - half)):
+                K, Fe, _ = mf.local_assemble(first, count)
+                assert mf.assembled_scatter(K, Fe, RP, CI, vals, rhs, first=first, skip_dirichlet=skip) == 0
         torch.cuda.synchronize()
         return sp.csr_matrix((vals.cpu().numpy(), col_ind, row_ptr), shape=(n, n)), rhs.cpu().numpy()
 
