@@ -318,9 +318,9 @@ int l3k_assembled_scatter(l3k_mf* mf, int64_t first, int64_t count, const double
 /* K_e of the elements [first, first+count) in the TILED layout that l3k_assemble_global keeps between its two kernels, for
  * consumers that do not need the reference's row-major matrix: per element the U x U blocks K[(b,u),(b',u')] with the nodes
  * b = bx + n(by + n bz), b' = bx' + n(by' + n bz') (n = order + 1) stored as [u][u'][bx'][bz][bx][by][by'][bz'], bz' fastest --
- * Nd^2 doubles as in the row-major layout, every entry present (no mirroring left to the reader).  A wave of the assembly
- * kernel writes 512 contiguous bytes per store (the row-major stores are 8-byte pieces at a stride of 8U bytes, measured
- * x3.9 write traffic), a reader finds a matrix row in 4n runs of n^2 doubles.  Shapes without the sum-factorised assembly
+ * Nd^2 doubles as in the row-major layout, every entry present (no mirroring left to the reader).  The stores of a wave of the
+ * assembly kernel fill contiguous memory (the row-major stores are 8-byte pieces at a stride of 8U bytes, measured x3.9
+ * write traffic), a reader finds a matrix row in 4n runs of n^2 doubles.  Shapes without the sum-factorised assembly
  * kernel (order 8) return an error. */
 int l3k_local_assemble_tiled(l3k_mf* mf, int64_t first, int64_t count, double* d_Kt);
 int l3k_assemble_global(l3k_mf* mf, int64_t first, int64_t count, const int64_t* d_row_ptr, const int32_t* d_col_ind,

@@ -386,8 +386,8 @@ __device__ __forceinline__ int opaqueOffset(int x)
     asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
     return y;
 }
-// TILED: all U x U blocks (no symmetry: a few FP64 instructions for a layout that a wave can WRITE in 512-byte pieces and a row
-// reader can READ in runs of n^2 doubles), stored as [u][u'][bx'][bz][bx][by][by'][bz'] -- row node b = (bx, by, bz), column node
+// TILED: all U x U blocks (no symmetry: more FP64 instructions for a layout in which the stores of a wave fill contiguous memory and
+// a row reader finds runs of n^2 doubles), stored as [u][u'][bx'][bz][bx][by][by'][bz'] -- row node b = (bx, by, bz), column node
 // b' = (bx', by', bz').  In the row-major layout of the reference every 64-byte line of K_e collects its 8 entries from four
 // workgroups and two iterations: measured write traffic 3.9 x the matrix (profiles/r03_tcc_assembly_stored.txt).
 template < typename K, int P, int NQ, bool TILED = false >
