@@ -268,7 +268,13 @@ typedef struct
 int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv);
 int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_minv, const l3k_cg_opts* opts,
                   l3k_cg_result* result);
-int l3k_cg_init(l3k_ctx* ctx, double* d_r, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s);
+/* The pieces of the iteration for hosts that reduce the scalars across ranks themselves (d_s: device block, 0 <r,z> old, 1 <p,Ap>,
+ * 2 <r,z> new, 3 <r,r>).  The iteration keeps the preconditioned residual z = M^-1 r instead of r (9 instead of 11 vector passes):
+ *   l3k_cg_init:      d_z holds A x0 on entry; z = minv (b - A x0), p = z, s[2] = <r,z>, s[3] = <r,r> (this rank's share)
+ *   l3k_cg_update_z:  alpha = s[0]/s[1]; z -= alpha minv Ap; s[2], s[3] as above (r = z / minv)
+ *   l3k_cg_update_px: x += alpha p; beta = s[2]/s[0]; p = z + beta p; then s[0] <- s[2]
+ * d_minv may be NULL (no preconditioner: z = r). */
+int l3k_cg_init(l3k_ctx* ctx, double* d_z, const double* d_b, double* d_p, const double* d_minv, int64_t n, double* d_s);
 int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t n, double* d_s);
 /* One rank, one column: y <- A x and s[1] <- <x, A x> in one pass (what the PCG needs of an apply followed by
  * l3k_cg_dot_pap).  On the single-wave route of domain kernels the element kernel accumulates x^T A x = sum_q w detJ |B_q x|^2
@@ -281,9 +287,8 @@ int l3k_mf_apply_energy(l3k_mf* mf, const double* d_x, double* d_y, double* d_s)
  * s[1] then holds this rank's share of <x, A x>; the all-reduce over the ranks is the caller's, as for the other scalars. */
 int l3k_mf_energy_begin(l3k_mf* mf, double* d_s);
 int l3k_mf_energy_end(l3k_mf* mf, const double* d_x, int* fused);
-int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
-                     int64_t n, double* d_s);
-int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s);
+int l3k_cg_update_z(l3k_ctx* ctx, double* d_z, const double* d_ap, const double* d_minv, int64_t n, double* d_s);
+int l3k_cg_update_px(l3k_ctx* ctx, double* d_p, double* d_x, const double* d_z, int64_t n, double* d_s);
 
 /* ---- LocalAssembly --------------------------------------------------------------------------------------------------
  * assembleLocalSystem for a batch of elements, algsys/AssembleLocalSystem.hpp:234-256: K_e row-major [Nd][Nd],

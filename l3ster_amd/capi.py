@@ -155,8 +155,8 @@ SIGNATURES = {
     "l3k_mf_apply_energy": (C.c_int, [_vp, _vp, _vp, _vp]),
     "l3k_mf_energy_begin": (C.c_int, [_vp, _vp]),
     "l3k_mf_energy_end": (C.c_int, [_vp, _vp, c_int_p]),
-    "l3k_cg_update_xr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
-    "l3k_cg_update_p": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_cg_update_z": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_cg_update_px": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "l3k_cube_partition_create": (C.c_int, [c_int_p, C.c_int, c_int_p, C.c_int, C.c_double, C.POINTER(_vp)]),
     "l3k_hostmesh_destroy": (C.c_int, [_vp]),
     "l3k_hostmesh_view_get": (C.c_int, [_vp, C.POINTER(HostMeshView)]),

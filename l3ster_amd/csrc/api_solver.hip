@@ -48,21 +48,27 @@ __global__ __launch_bounds__(cg_threads) void cgFinishKernel(const double* __res
     if (shift && threadIdx.x == 0)
         s[0] = s[2];
 }
-// alpha = s[0]/s[1]; x += alpha p; r -= alpha Ap; partial <r, minv r>, <r, r>
-__global__ __launch_bounds__(cg_threads) void cgUpdateXRKernel(double* __restrict__ x, double* __restrict__ r,
-                                                               const double* __restrict__ p, const double* __restrict__ ap,
-                                                               const double* __restrict__ minv, int64_t n,
-                                                               const double* __restrict__ s, double* __restrict__ partial)
+// The iteration keeps the PRECONDITIONED residual z = M^-1 r instead of r (Jacobi: r = z / minv element-wise), and x moves in the
+// p pass: 9 vector passes per iteration instead of 11 (the vector kernels run at the HBM rate, so passes are what counts):
+//   z pass:  alpha = s[0]/s[1]; z -= alpha minv Ap; partial <r, z>, <r, r> with r = z / minv     reads z, Ap, minv; writes z
+//   p pass:  x += alpha p; beta = s[2]/s[0]; p = z + beta p                                       reads z, p, x;   writes p, x
+// (round 2: x += alpha p and r -= alpha Ap in one pass over x, r, p, Ap, minv, then p = minv r + beta p over r, minv, p.)
+// The same iterates in exact arithmetic; in floating point z is updated where r was (one rounding of minv * Ap more, one of
+// minv * r less).
+__global__ __launch_bounds__(cg_threads) void cgUpdateZKernel(double* __restrict__ z, const double* __restrict__ ap,
+                                                              const double* __restrict__ minv, int64_t n,
+                                                              const double* __restrict__ s, double* __restrict__ partial)
 {
     __shared__ double sh[cg_threads];
     const double      alpha = s[0] / s[1];
     double            rz = 0., rr = 0.;
     for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
     {
-        x[i] += alpha * p[i];
-        const double ri = r[i] - alpha * ap[i];
-        r[i]            = ri;
-        rz += ri * (minv ? minv[i] * ri : ri);
+        const double m  = minv ? minv[i] : 1.;
+        const double zi = z[i] - alpha * (m * ap[i]);
+        const double ri = minv ? zi / m : zi;
+        z[i]            = zi;
+        rz += ri * zi;
         rr += ri * ri;
     }
     const double a = blockSum(rz, sh);
@@ -74,15 +80,18 @@ __global__ __launch_bounds__(cg_threads) void cgUpdateXRKernel(double* __restric
         partial[gridDim.x + blockIdx.x] = b;
     }
 }
-// beta = s[2]/s[0]; p = minv r + beta p
-__global__ __launch_bounds__(cg_threads) void cgUpdatePKernel(double* __restrict__ p, const double* __restrict__ r,
-                                                              const double* __restrict__ minv, int64_t n, const double* __restrict__ s)
+__global__ __launch_bounds__(cg_threads) void cgUpdatePXKernel(double* __restrict__ p, double* __restrict__ x, const double* __restrict__ z,
+                                                               int64_t n, const double* __restrict__ s)
 {
-    const double beta = s[2] / s[0];
+    const double alpha = s[0] / s[1], beta = s[2] / s[0];
     for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
-        p[i] = (minv ? minv[i] * r[i] : r[i]) + beta * p[i];
+    {
+        const double pi = p[i];
+        x[i] += alpha * pi;
+        p[i] = z[i] + beta * pi;
+    }
 }
-// r = b - r (r holds A x0 on entry); z-free start: p = minv r; partial <r, minv r>, <r, r>
+// z = minv (b - r) (r holds A x0 on entry and z on return); p = z; partial <r, z>, <r, r>
 __global__ __launch_bounds__(cg_threads) void cgInitKernel(double* __restrict__ r, const double* __restrict__ b,
                                                            double* __restrict__ p, const double* __restrict__ minv, int64_t n,
                                                            double* __restrict__ partial)
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(cg_threads) void cgInitKernel(double* __restrict__ 
     {
         const double ri = b[i] - r[i];
         const double zi = minv ? minv[i] * ri : ri;
-        r[i]            = ri;
+        r[i]            = zi;
         p[i]            = zi;
         rz += ri * zi;
         rr += ri * ri;
@@ -177,32 +186,31 @@ int l3k_cg_dot_pap(l3k_ctx* ctx, const double* d_p, const double* d_ap, int64_t 
     L3K_HIP(hipGetLastError());
     return 0;
 }
-int l3k_cg_update_xr(l3k_ctx* ctx, double* d_x, double* d_r, const double* d_p, const double* d_ap, const double* d_minv,
-                     int64_t n, double* d_s)
+int l3k_cg_update_z(l3k_ctx* ctx, double* d_z, const double* d_ap, const double* d_minv, int64_t n, double* d_s)
 {
-    if (!ctx || !d_x || !d_r || !d_p || !d_ap || !d_s)
+    if (!ctx || !d_z || !d_ap || !d_s)
     {
-        setError("l3k_cg_update_xr: null argument");
+        setError("l3k_cg_update_z: null argument");
         return -1;
     }
     if (int rc = cgWorkspace(ctx))
         return rc;
     const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgUpdateXRKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_x, d_r, d_p, d_ap, d_minv, n, d_s, ctx->red_ws);
+    hipLaunchKernelGGL(cgUpdateZKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_z, d_ap, d_minv, n, d_s, ctx->red_ws);
     hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, g, d_s, 2, 3, 0);
     L3K_HIP(hipGetLastError());
     return 0;
 }
-int l3k_cg_update_p(l3k_ctx* ctx, double* d_p, const double* d_r, const double* d_minv, int64_t n, double* d_s)
+int l3k_cg_update_px(l3k_ctx* ctx, double* d_p, double* d_x, const double* d_z, int64_t n, double* d_s)
 {
-    if (!ctx || !d_p || !d_r || !d_s)
+    if (!ctx || !d_p || !d_x || !d_z || !d_s)
     {
-        setError("l3k_cg_update_p: null argument");
+        setError("l3k_cg_update_px: null argument");
         return -1;
     }
     const int g = cgGrid(n);
-    hipLaunchKernelGGL(cgUpdatePKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_r, d_minv, n, d_s);
-    // <r,z> of this iteration becomes the old one: after every block has read both
+    hipLaunchKernelGGL(cgUpdatePXKernel, dim3(g), dim3(cg_threads), 0, ctx->stream, d_p, d_x, d_z, n, d_s);
+    // <r,z> of this iteration becomes the old one: after every block has read alpha and beta
     hipLaunchKernelGGL(cgFinishKernel, dim3(1), dim3(cg_threads), 0, ctx->stream, ctx->red_ws, 0, d_s, 4, -1, 1);
     L3K_HIP(hipGetLastError());
     return 0;
@@ -225,7 +233,7 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
     l3k_ctx*          ctx = mf->ctx;
     hipStream_t       st  = ctx->stream;
     const int64_t     n   = mf->mesh->nOwnedDofs();
-    DevBuf< double >  work; // r | p | ap | s[8]
+    DevBuf< double >  work; // z (the preconditioned residual, in the array named r) | p | ap | s[8]
     work.n = size_t(3 * n + 8);
     L3K_HIP(hipMalloc(reinterpret_cast< void** >(&work.ptr), work.n * sizeof(double)));
     double *r = work.ptr, *p = r + n, *ap = p + n, *s = ap + n;
@@ -235,7 +243,7 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
         L3K_HIP(hipStreamSynchronize(st));
         return 0;
     };
-    // r = b - A x0, p = z = M^-1 r
+    // z = M^-1 (b - A x0), p = z
     if (int rc = l3k_mf_apply(mf, d_x, size_t(n), r, size_t(n), 1, 1., 0.))
         return rc;
     if (int rc = l3k_cg_init(ctx, r, d_b, p, d_minv, n, s))
@@ -260,9 +268,9 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
     {
         if (int rc = l3k_mf_apply_energy(mf, p, ap, s)) // ap = A p, s[1] = <p, A p>
             return rc;
-        if (int rc = l3k_cg_update_xr(ctx, d_x, r, p, ap, d_minv, n, s))
+        if (int rc = l3k_cg_update_z(ctx, r, ap, d_minv, n, s)) // (r holds z = M^-1 r)
             return rc;
-        if (int rc = l3k_cg_update_p(ctx, p, r, d_minv, n, s))
+        if (int rc = l3k_cg_update_px(ctx, p, d_x, r, n, s))
             return rc;
         ++it;
         if (it % every == 0 || it == o.max_iters)

@@ -142,9 +142,9 @@ def pcg_distributed(op, ctx, b, x, minv=None, tol=1e-6, max_iters=10_000, residu
         if not fuse_energy:
             capi.check(lib.l3k_cg_dot_pap(ctx._h, vp(p), vp(ap), n, vp(s)))
         reduce(s[1:2])
-        capi.check(lib.l3k_cg_update_xr(ctx._h, vp(x), vp(r), vp(p), vp(ap), vp(minv), n, vp(s)))
+        capi.check(lib.l3k_cg_update_z(ctx._h, vp(r), vp(ap), vp(minv), n, vp(s)))  # (r holds z = M^-1 r: l3k.h)
         reduce(s[2:4])
-        capi.check(lib.l3k_cg_update_p(ctx._h, vp(p), vp(r), vp(minv), n, vp(s)))
+        capi.check(lib.l3k_cg_update_px(ctx._h, vp(p), vp(x), vp(r), n, vp(s)))
         it += 1
         if it % check_every == 0 or it == max_iters:  # (the only host synchronisation of the iteration)
             res = s[3].item() ** 0.5 / scale
