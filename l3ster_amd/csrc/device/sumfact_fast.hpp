@@ -224,8 +224,8 @@ struct FastCfg
 // SPLIT: ghost rows live in buffers of their own (a.xg / a.yg, the reference's import / export buffers): every node needs
 // an owned-or-ghost select.  SPLIT = false (no ghost buffers in this launch -- one rank, or interior elements -- or ghost
 // rows directly behind the owned rows): one base pointer, ~150 instructions per element less.
-// ENERGY: the kernel also accumulates x^T A x = sum_q wgt |B x|^2 of its elements into *a.energy (for <p, A p> of the PCG:
-// saves the separate dot-product pass over two vectors).
+// ENERGY: the kernel also accumulates x^T A x of its elements into *a.energy (for <p, A p> of the PCG: saves the separate
+// dot-product pass over two vectors): per element x_e . y_e, formed where the result leaves the registers (I^T z stage).
 // AFFINE: every element of the launch is a parallelepiped (its tri-linear map is affine: l3k_mesh_create checks the vertices):
 // one Jacobian per element, inverted once per element instead of once per quadrature point.
 // MULTI: a.n_cols columns per element pass (the reference applies all n_rhs columns in one sweep over the elements,
@@ -653,7 +653,6 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
         if (w_qq)
         {
-            [[maybe_unused]] double en = 0.; // ENERGY: this pencil's share of x^T A x
             // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers.)  alpha rides on the weight, so the
             // staged result needs no scaling pass; the ENERGY variant accumulates the unscaled x^T A x and scales at the end
             const double wyz = opaqueCopy(wyz_l) * (ENERGY ? 1. : a.alpha);
@@ -718,10 +717,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 if constexpr (AFFINE)
                 {
                     const double xyz[3] = {G[0][0] + qp[q] * G[1][0], G[0][1] + qp[q] * G[1][1], G[0][2] + qp[q] * G[1][2]};
-                    qpStageAt< K, 1, false, 1, 0, ENERGY >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                    qpStageAt< K, 1, false, 1, 0, false >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, nullptr);
                 }
                 else
-                    qpStage< K, 1, false, 1, 0, ENERGY >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                    qpStage< K, 1, false, 1, 0, false >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -736,8 +735,6 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 }
             }
             }
-            if constexpr (ENERGY) // LDS atomic add of every pencil's share into the team's accumulator
-                atomicAdd(vs + 24, en);
         }
         stageFence();
         L3K_STAMP(6);
@@ -883,6 +880,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             double tIt[2 * HQ * HN];
             loadTable(tIt, eoIt + opaqueZero());
             double*       sb  = reinterpret_cast< double* >(bufB);
+            [[maybe_unused]] double              en_e  = 0.;
+            [[maybe_unused]] const double* const ax_e  = a.x;
+            [[maybe_unused]] const double* const axg_e = a.xg;
             const uint4   srow = slotRows[l]; // scatter slots of this lane's N1 nodes
             const uint32_t sw[4] = {srow.x, srow.y, srow.z, srow.w};
             // (GB field groups per block: their LDS reads are issued before the first group's sweeps)
@@ -912,8 +912,33 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     double*        dstl = sb + slot * U + 2 * g;
                     *reinterpret_cast< double2* >(dstl) = ENERGY ? make_double2(a.alpha * o0[k], a.alpha * o1[k]) : make_double2(o0[k], o1[k]); // (U is even)
                 }
+                if constexpr (ENERGY)
+                {
+                    // x^T A x of this element = x_e . y_e: this lane holds the (unscaled) result of exactly the nodes it gathered,
+                    // so its share is a dot product with their x values, fetched once more here (L2 hits: the element's rows
+                    // were read at the top of the element) -- the accumulation inside the quadrature stage, where no register is
+                    // free, made this variant spill (12 registers at order 6, 10 for config 5's kernel at order 4).  Dirichlet
+                    // dofs were gathered as 0 and are skipped by the scatter: they do not take part
+#pragma unroll
+                    for (int k = 0; k < N1; ++k)
+                    {
+                        // (an opaque copy of the id: with the plain one the compiler merges this load with the gather's and keeps
+                        // the element's x values in registers across all stages -- 34 spilled registers)
+                        const int64_t node = static_cast< uint32_t >(opaqueCopy(static_cast< int >(ids_cur[k])));
+                        const double* px   = (!SPLIT || node < n_owned_nodes ? ax_e + node * U : axg_e + (node - n_owned_nodes) * U) + 2 * g;
+                        double2       xv   = *reinterpret_cast< const double2* >(px);
+                        if ((flag_cur & 1u) != 0)
+                        {
+                            xv.x = a.dirichlet[node * U + 2 * g] != 0 ? 0. : xv.x;
+                            xv.y = a.dirichlet[node * U + 2 * g + 1] != 0 ? 0. : xv.y;
+                        }
+                        en_e += xv.x * o0[k] + xv.y * o1[k];
+                    }
+                }
             }
             }
+            if constexpr (ENERGY) // LDS atomic add of every lane's share into the team's accumulator
+                atomicAdd(vs + 24, en_e);
         }
         stageFence();
         L3K_STAMP(10);
