@@ -240,6 +240,13 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
+    // ENERGY: x^T A x either inside the quadrature stage (sum_q wgt |B x|^2: an accumulator where no register is free) or as
+    // x_e . y_e where the result leaves the registers (a second fetch of the element's x rows).  Measured per shape
+#ifdef L3K_ENERGY_AT_END
+    constexpr bool ENERGY_AT_END = L3K_ENERGY_AT_END != 0;
+#else
+    constexpr bool ENERGY_AT_END = EW == 1;
+#endif
     constexpr int HN = (N1 + 1) / 2, HQ = (NQ + 1) / 2;
     constexpr int GB = Cfg::read_block; // field groups whose LDS reads are batched (register cost: 2 * N1 doubles per extra group)
     // with fewer derivative groups than groups, buffer B is too small for the y / x interpolation of all groups: those two
@@ -653,6 +660,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         // ---- quadrature points of the x-pencil (qy, qz) = (qa, qb): evalAtHexQPs, SumFactorization.hpp:707-753
         if (w_qq)
         {
+            [[maybe_unused]] double en = 0.; // ENERGY (in-stage form): this pencil's share of x^T A x
             // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers.)  alpha rides on the weight, so the
             // staged result needs no scaling pass; the ENERGY variant accumulates the unscaled x^T A x and scales at the end
             const double wyz = opaqueCopy(wyz_l) * (ENERGY ? 1. : a.alpha);
@@ -717,10 +725,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 if constexpr (AFFINE)
                 {
                     const double xyz[3] = {G[0][0] + qp[q] * G[1][0], G[0][1] + qp[q] * G[1][1], G[0][2] + qp[q] * G[1][2]};
-                    qpStageAt< K, 1, false, 1, 0, false >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, nullptr);
+                    qpStageAt< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
                 }
                 else
-                    qpStage< K, 1, false, 1, 0, false >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd);
+                    qpStage< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -735,6 +743,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 }
             }
             }
+            if constexpr (ENERGY && !ENERGY_AT_END) // LDS atomic add of every pencil's share into the team's accumulator
+                atomicAdd(vs + 24, en);
         }
         stageFence();
         L3K_STAMP(6);
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     double*        dstl = sb + slot * U + 2 * g;
                     *reinterpret_cast< double2* >(dstl) = ENERGY ? make_double2(a.alpha * o0[k], a.alpha * o1[k]) : make_double2(o0[k], o1[k]); // (U is even)
                 }
-                if constexpr (ENERGY)
+                if constexpr (ENERGY && ENERGY_AT_END)
                 {
                     // x^T A x of this element = x_e . y_e: this lane holds the (unscaled) result of exactly the nodes it gathered,
                     // so its share is a dot product with their x values, fetched once more here (L2 hits: the element's rows
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 }
             }
             }
-            if constexpr (ENERGY) // LDS atomic add of every lane's share into the team's accumulator
+            if constexpr (ENERGY && ENERGY_AT_END) // LDS atomic add of every lane's share into the team's accumulator
                 atomicAdd(vs + 24, en_e);
         }
         stageFence();
