@@ -11,7 +11,7 @@ import torch
 import oracle_lib as O
 from helpers import oracle_mesh
 from l3ster_amd import system
-from l3ster_amd.distributed import DistributedOperator, HaloPlan
+from l3ster_amd.distributed import DistributedOperator, HaloPlan, InprocGroup, NativeDistributedOperator, NativeHalo
 
 
 class ThreadTransport:
@@ -33,6 +33,8 @@ class ThreadTransport:
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--native", action="store_true", help="the C-ABI schedule l3k_mf_apply_dist with the library's in-process transport "
+                                                        "(round 3) instead of the Python-side schedule")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 torch.cuda.set_device(0)
@@ -52,6 +54,7 @@ while time.time() < t_end:
     alpha, beta = float(rng.uniform(-2, 2)), float(rng.choice([0.0, rng.uniform(-1, 1)]))
     os.environ["L3K_GENERIC_BELOW"] = str(int(rng.choice([0, 1500])))
     boxes = {(i, j): queue.Queue() for i in range(world) for j in range(world)}
+    group = InprocGroup(world) if a.native else None
     out, errors = {}, []
 
     def run(rank):
@@ -64,7 +67,15 @@ while time.time() < t_end:
             n_owned = part.n_owned_nodes * U
             X = dev(part.synthetic_vector(U)[:, :n_owned])
             Y = dev(part.synthetic_vector(U, seed=7)[:, :n_owned])
-            DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes)).apply(X, Y, alpha, beta)
+            if a.native:
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    c2 = system.Context(0, torch.cuda.current_stream().cuda_stream)
+                    mf2 = system.MatrixFreeSystem(system.DeviceMesh(c2, part, U, mask), kid, [0.7, 1.0])
+                    torch.cuda.current_stream().wait_stream(torch.cuda.default_stream())
+                    NativeDistributedOperator(mf2, NativeHalo(c2, part, U, rank, world, transport=group)).apply(X, Y, alpha, beta)
+                    torch.cuda.current_stream().synchronize()
+            else:
+                DistributedOperator(mf, HaloPlan(part, U, "cuda"), transport=ThreadTransport(rank, boxes)).apply(X, Y, alpha, beta)
             torch.cuda.synchronize()
             out[rank] = (Y.cpu().numpy(), part.node_grid_id[:part.n_owned_nodes].copy())
         except Exception as exc:
