@@ -180,6 +180,30 @@ constexpr bool kernelUsesFieldDers()
         return true;
 }
 
+// bit u of the result: dof u of the node is a Dirichlet dof (mask bytes [node * U, node * U + U), one load where U allows it)
+template < int U >
+__device__ __forceinline__ uint32_t dirichletBits(const uint8_t* __restrict__ mask, int64_t node)
+{
+    if constexpr (U == 4)
+    {
+        const uint32_t w = *reinterpret_cast< const uint32_t* >(mask + node * 4);
+        return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+    }
+    else if constexpr (U == 2)
+    {
+        const uint32_t w = *reinterpret_cast< const uint16_t* >(mask + node * 2);
+        return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u);
+    }
+    else
+    {
+        uint32_t dm = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            dm |= uint32_t(mask[node * U + u] != 0) << u;
+        return dm;
+    }
+}
+
 template < typename K, int P, int NQ >
 struct FastCfg
 {
@@ -242,7 +266,9 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
     // ENERGY: x^T A x either inside the quadrature stage (sum_q wgt |B x|^2: an accumulator where no register is free) or as
     // x_e . y_e where the result leaves the registers (a second fetch of the element's x rows).  Measured per shape
-#ifdef L3K_ENERGY_AT_END
+#if defined(L3K_FLAGGED_SCATTER)
+    constexpr bool ENERGY_AT_END = false; // (the A/B form does not zero the staged Dirichlet dofs, which x_e . y_e relies on)
+#elif defined(L3K_ENERGY_AT_END)
     constexpr bool ENERGY_AT_END = L3K_ENERGY_AT_END != 0;
 #else
     constexpr bool ENERGY_AT_END = EW == 1;
@@ -387,14 +413,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 xn[k][2 * hh]     = t.x;
                 xn[k][2 * hh + 1] = t.y;
             }
-            uint32_t dm = 0;
-            if (flagged)
-            {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    dm |= uint32_t(a.dirichlet[node * U + u] != 0) << u;
-            }
-            dm_nxt[k] = dm;
+            dm_nxt[k] = flagged ? dirichletBits< U >(a.dirichlet, node) : 0u;
 #pragma unroll
             for (int f = 0; f < F; ++f)
                 fn[k][f] = a.fields[node + f * a.ldf];
@@ -915,6 +934,26 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 double o0[N1], o1[N1];
                 sweepEO< NQ, N1, false, false >(in0[g - gb], o0, tIt);
                 sweepEO< NQ, N1, false, false >(in1[g - gb], o1, tIt);
+                // scatterSumFact skips Dirichlet dofs (MatrixFreeSystem.hpp:517-536).  Here their staged values become 0 -- the
+                // scatter then ADDS 0 to those rows (or stores beta * y on exclusive ones), which leaves them as they are -- so
+                // that elements touching the Dirichlet boundary take the same unrolled scatter as all others (they used to loop
+                // with a mask byte load per dof and round: the chunks holding Dirichlet faces ran 7 % longer).  The mask bytes
+                // are fetched again here instead of kept from the gather (registers)
+#ifndef L3K_FLAGGED_SCATTER // (A/B switch: the round-2 form with a scatter path of its own for flagged elements)
+                if ((flag_cur & 1u) != 0)
+#else
+                if (false)
+#endif
+                {
+#pragma unroll
+                    for (int k = 0; k < N1; ++k)
+                    {
+                        const int64_t  node = static_cast< uint32_t >(opaqueCopy(static_cast< int >(ids_cur[k])));
+                        const uint32_t dmk  = dirichletBits< U >(a.dirichlet, node) >> (2 * g);
+                        o0[k]               = (dmk & 1u) ? 0. : o0[k];
+                        o1[k]               = (dmk & 2u) ? 0. : o1[k];
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < N1; ++k)
                 {
@@ -936,13 +975,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                         // the element's x values in registers across all stages -- 34 spilled registers)
                         const int64_t node = static_cast< uint32_t >(opaqueCopy(static_cast< int >(ids_cur[k])));
                         const double* px   = (!SPLIT || node < n_owned_nodes ? ax_e + node * U : axg_e + (node - n_owned_nodes) * U) + 2 * g;
-                        double2       xv   = *reinterpret_cast< const double2* >(px);
-                        if ((flag_cur & 1u) != 0)
-                        {
-                            xv.x = a.dirichlet[node * U + 2 * g] != 0 ? 0. : xv.x;
-                            xv.y = a.dirichlet[node * U + 2 * g + 1] != 0 ? 0. : xv.y;
-                        }
-                        en_e += xv.x * o0[k] + xv.y * o1[k];
+                        const double2 xv   = *reinterpret_cast< const double2* >(px);
+                        en_e += xv.x * o0[k] + xv.y * o1[k]; // (o0, o1 are 0 on Dirichlet dofs: zeroed above)
                     }
                 }
             }
@@ -986,7 +1020,12 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             const double* const   sb      = lds + size_t(steam_s) * Cfg::TEAM_D + Cfg::BUF_D;
             const uint32_t* const idsS    = reinterpret_cast< const uint32_t* >(lds + size_t(steam_s) * Cfg::TEAM_D);
+            // (Dirichlet dofs were zeroed when the result was staged: every element takes the common path)
+#ifndef L3K_FLAGGED_SCATTER
+            constexpr bool        flagged = false;
+#else
             const bool            flagged = (flag_cur & 2u) != 0;
+#endif
             // (SG is a multiple of U: a lane keeps its unknown and moves SG / U slots per round -- every LDS address below is
             // one per-lane base plus a compile-time offset)
             static_assert(SG % U == 0);
