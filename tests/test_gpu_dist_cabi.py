@@ -69,7 +69,7 @@ def test_mf_apply_dist_thread_ranks_inproc_transport(ne, p, parts, ncols):
     from l3ster_amd.distributed import InprocGroup, NativeDistributedOperator, NativeHalo
     world = int(np.prod(parts))
     group = InprocGroup(world)
-    out = {}
+    out, exported = {}, {}
 
     def body(rank):
         part = system.CubePartition(ne, p, parts, rank, perturb=0.1)
@@ -86,6 +86,11 @@ def test_mf_apply_dist_thread_ranks_inproc_transport(ne, p, parts, ncols):
         torch.cuda.current_stream().synchronize()
         want = part.synthetic_vector(U, ncols=ncols)[:, n_owned:]
         assert np.array_equal(ghosts.cpu().numpy()[:, :want.shape[1]], want)
+        # comm::Export alone: every ghost row of value 1 lands in exactly one owner's row (summed over the ranks below)
+        acc = torch.zeros_like(X)
+        op.export_add(torch.ones_like(ghosts), acc)
+        torch.cuda.current_stream().synchronize()
+        exported[rank] = (float(acc.sum()), part.n_ghost_nodes * U * ncols)
         for _ in range(20):
             Yc = Y.clone()
             op.apply(X, Yc, 1.25, -0.5)
@@ -93,6 +98,7 @@ def test_mf_apply_dist_thread_ranks_inproc_transport(ne, p, parts, ncols):
         out[rank] = (Yc.cpu().numpy(), part.node_grid_id[:part.n_owned_nodes].copy())
 
     run_ranks(world, body)
+    assert sum(v[0] for v in exported.values()) == sum(v[1] for v in exported.values()) > 0
     whole = system.CubePartition(ne, p, perturb=0.1)
     mask = whole.dirichlet_mask(U)
     x, y0 = whole.synthetic_vector(U, ncols=ncols), whole.synthetic_vector(U, seed=7, ncols=ncols)
