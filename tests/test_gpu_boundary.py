@@ -343,4 +343,7 @@ def test_partitioned_solve_end_to_end(S, ctx, ne, parts, adiabatic):
     assert len(iters) == 1  # every rank saw the same reduced scalars
     for r in range(world):
         assert out[r][1] < 1e-9 and out[r][2] < 1e-8 and out[r][3] < 1e-8, (r, out[r])
-        assert out[r][4] == (not adiabatic), (r, out[r])
+        # <p, A p> from the element kernels unless a boundary term is attached -- or the run is in deterministic mode, which
+        # takes the fixed-order dot product instead
+        import os
+        assert out[r][4] == (not adiabatic and not os.environ.get("L3K_DETERMINISTIC")), (r, out[r])
