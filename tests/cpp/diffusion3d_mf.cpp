@@ -79,6 +79,39 @@ int main()
         }
         std::printf("single element: |y - K_e x| / |K_e x| = %.3e\n", std::sqrt(err / nrm));
         failures += !(std::sqrt(err / nrm) < 1e-12);
+        // assembleGlobalSystem in one call: with one element the global matrix over a dense graph in global dof order is K_e
+        // with its rows and columns renumbered
+        std::vector< int64_t > row_ptr(Nd + 1);
+        std::vector< int32_t > col_ind(size_t(Nd) * Nd);
+        for (int i = 0; i <= Nd; ++i)
+            row_ptr[size_t(i)] = int64_t(i) * Nd;
+        for (int i = 0; i < Nd; ++i)
+            for (int j = 0; j < Nd; ++j)
+                col_ind[size_t(i) * Nd + j] = j;
+        int64_t* d_rp = nullptr;
+        int32_t* d_ci = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast< void** >(&d_rp), row_ptr.size() * sizeof(int64_t)));
+        HIP_CHECK(hipMalloc(reinterpret_cast< void** >(&d_ci), col_ind.size() * sizeof(int32_t)));
+        HIP_CHECK(hipMemcpy(d_rp, row_ptr.data(), row_ptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_ci, col_ind.data(), col_ind.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        DevVec dV{size_t(Nd) * Nd}, dR{Nd};
+        HIP_CHECK(hipMemset(dV.p, 0, sizeof(double) * size_t(Nd) * Nd));
+        HIP_CHECK(hipMemset(dR.p, 0, sizeof(double) * Nd));
+        const int64_t missing = sys.assembleGlobal(0, 1, d_rp, d_ci, dV.p, dR.p, Nd);
+        ctx.synchronize();
+        const auto V = dV.down();
+        double     gerr = 0., gmax = 0.;
+        for (int i = 0; i < Nd; ++i)
+            for (int j = 0; j < Nd; ++j)
+            {
+                const size_t gi = mesh.view().elem_nodes[i / U] * U + i % U, gj = mesh.view().elem_nodes[j / U] * U + j % U;
+                gerr = std::max(gerr, std::fabs(V[gi * Nd + gj] - K[size_t(i) * Nd + j]));
+                gmax = std::max(gmax, std::fabs(K[size_t(i) * Nd + j]));
+            }
+        std::printf("assembleGlobal (one call): max |A - K_e| / |K_e|_max = %.3e, %lld entries outside the graph\n", gerr / gmax, (long long)missing);
+        failures += !(gerr < 1e-13 * gmax && missing == 0);
+        (void)hipFree(d_rp);
+        (void)hipFree(d_ci);
     }
     { // (2) 4^3 elements, order 4, Dirichlet on unknown 0: symmetry
         constexpr int         p = 4, U = 4;
