@@ -74,9 +74,9 @@ __global__ __launch_bounds__(384, 3) void spinTrace(double* p, int n, unsigned l
 #include <map>
 #include <string>
 #include <vector>
-void trace(int threads, int cus, double* d)
+void trace(int threads, int cus, double* d, int lds = 79576)
 {
-    const int lds = 79576, grid = 4 * cus, wpb = threads / 64;
+    const int grid = 16 * cus * 64 / threads > 4 * cus ? 16 * cus * 64 / threads : 4 * cus, wpb = threads / 64;
     hipFuncSetAttribute(reinterpret_cast< const void* >(spinTrace), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     unsigned long long* rec;
     hipMalloc(&rec, size_t(grid) * wpb * 32);
@@ -118,7 +118,7 @@ void trace(int threads, int cus, double* d)
             mx = std::max(mx, cur += e.second);
         ++hist[mx];
     }
-    std::printf("trace, %d waves per workgroup, ~150 VGPRs, LDS %d B, grid 4 x CUs: %zu distinct CUs seen;", wpb, lds, ev.size());
+    std::printf("trace, %d waves per workgroup, ~150 VGPRs, LDS %d B, grid of %d: %zu distinct CUs seen;", wpb, lds, grid, ev.size());
     for (auto& [m, c] : hist)
         std::printf(" %d CUs with at most %d workgroups resident at once;", c, m);
     std::printf(" waves per SIMD of a workgroup:");
@@ -183,5 +183,12 @@ int main()
     trace(384, cus, d);
     trace(256, cus, d);
     trace(320, cus, d);
+    // small workgroups, LDS not limiting: is the register accounting per SIMD?
+    trace(64, cus, d, 4096);
+    trace(128, cus, d, 4096);
+    trace(192, cus, d, 4096);
+    trace(256, cus, d, 4096);
+    trace(320, cus, d, 4096);
+    trace(384, cus, d, 4096);
     return 0;
 }
