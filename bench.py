@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from l3ster_amd import system  # noqa: E402
-from l3ster_amd.distributed import DistributedOperator, HaloPlan, NativeDistributedOperator, NativeHalo  # noqa: E402
+from l3ster_amd.distributed import DistributedOperator, HaloPlan, HostStagedTransport, NativeDistributedOperator, NativeHalo  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
@@ -137,13 +137,22 @@ def main():
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
+    # L3K_BENCH_REHEARSAL=1: all ranks on GPU 0 with the gloo backend -- the N > 1 code path (partition, exchange lists, split-phase
+    # schedule, reductions over ranks, this JSON line) end to end on a one-GPU box; RCCL refuses two ranks on one device.  The
+    # numbers of such a run mean nothing and the line says so ("rehearsal": true).
+    rehearsal = os.environ.get("L3K_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("L3K_FORCE_DIST") == "1"  # the latter: smoke-test of the N > 1 code path at N = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     p, U, kid = args.order, 4, system.KERNEL_DIFFUSION3D
     parts = PARTS[world]
@@ -175,13 +184,13 @@ def main():
             except Exception as exc:  # pragma: no cover
                 ok = 0
                 print(f"[bench rank {rank}] native halo unavailable ({exc}); torch.distributed transport", file=sys.stderr, flush=True)
-            agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+            agree = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearsal else dev)
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
             native = bool(agree.item())
         if native:
             op = NativeDistributedOperator(mf, NativeHalo(ctx, part, U, rank, world))
         else:
-            op = DistributedOperator(mf, HaloPlan(part, U, dev))
+            op = DistributedOperator(mf, HaloPlan(part, U, dev), transport=HostStagedTransport() if rehearsal else None)
     t_setup = time.perf_counter() - t_setup
 
     n_launches = 3 if op is not None else 1  # partitioned: first interior half, border elements, second interior half
@@ -218,7 +227,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -230,7 +239,7 @@ def main():
     else:
         kernel_times = [sum(a.elapsed_time(b) for a, b in e) for e in ev]
     if use_dist:
-        kt = torch.tensor(kernel_times, dtype=torch.float64, device=dev)
+        kt = torch.tensor(kernel_times, dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kernel_times = kt.tolist()
     ms = float(np.median(kernel_times))  # median of the timed steps
@@ -241,7 +250,7 @@ def main():
         "metric": "DOF/s for MF operator apply (Diffusion3D, hex p=6)" if p == 6 else f"DOF/s for MF operator apply (Diffusion3D, hex p={p})",
         "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", **({"rehearsal": True} if rehearsal else {}),
         "config": {"workload": f"Diffusion3D matrix-free sum-factorised apply, hex mesh {ne_global[0]}x{ne_global[1]}x{ne_global[2]}, "
                                f"order {p}, U=4 E=7, {global_dofs} global dofs, {args.ne}^3 elements per GPU, "
                                f"partition {parts[0]}x{parts[1]}x{parts[2]}",
@@ -347,6 +356,23 @@ def main():
                 result["config"]["parity_sample"] = "the whole output vector of the benchmark mesh"
                 if not err < 1e-11:
                     raise SystemExit(f"GPU result differs from the oracle: rel L2 {err}")
+    if rehearsal and use_dist:
+        # the partitioned result against ONE rank's apply on the whole mesh (same global numbering, perturbation and x): x^T A x
+        # over the owned rows of all ranks, and the norm of y
+        loc = torch.stack([(X * Y).sum(), (Y * Y).sum()]).cpu()
+        dist.all_reduce(loc)
+        if rank == 0:
+            whole = system.CubePartition(ne_global, p, perturb=0.1)
+            mfw = system.MatrixFreeSystem(system.DeviceMesh(ctx, whole, U, whole.dirichlet_mask(U)), kid, [1.0, 1.0])
+            Xw = system.synthetic_vector_torch(whole.node_grid_id[:whole.n_owned_nodes], U, dev)
+            Yw = torch.empty_like(Xw)
+            mfw.apply(Xw, Yw, 1.0, 0.0)
+            ref = torch.stack([(Xw * Yw).sum(), (Yw * Yw).sum()]).cpu()
+            rel = ((loc - ref).abs() / ref.abs()).max().item()
+            result["rehearsal_check"] = {"xAx_and_yy_vs_one_rank_rel": rel, "xAx": loc[0].item()}
+            if not rel < 1e-11:
+                raise SystemExit(f"partitioned apply differs from the one-rank apply on the whole mesh: {rel}")
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()

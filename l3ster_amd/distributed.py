@@ -57,6 +57,31 @@ class TorchDistTransport:
             r.wait()
 
 
+class HostStagedTransport:
+    """The same exchange for device tensors over a backend that only moves host memory (gloo): every message goes through a
+    host copy.  For rehearsals of the multi-rank schedule with several ranks on ONE GPU (bench.py L3K_BENCH_REHEARSAL=1; RCCL
+    refuses two ranks on one device) -- never the measured path."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def post(self, sends, recvs):
+        torch.cuda.synchronize()  # the packed rows are on the stream
+        host_s = [(peer, t.detach().to("cpu").contiguous()) for peer, t in sends]
+        host_r = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
+        ops = [dist.P2POp(dist.isend, h, peer, self.group) for peer, h in host_s]
+        ops += [dist.P2POp(dist.irecv, h, peer, self.group) for peer, _, h in host_r]
+        return (dist.batch_isend_irecv(ops) if ops else [], host_s, host_r)
+
+    @staticmethod
+    def wait(handle):
+        reqs, _keep, host_r = handle
+        for r in reqs:
+            r.wait()
+        for _, t, h in host_r:
+            t.copy_(h)
+
+
 class DistributedOperator:
     def __init__(self, backend, plan, group=None, transport=None):
         self.backend, self.plan = backend, plan
