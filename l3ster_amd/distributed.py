@@ -66,7 +66,8 @@ class HostStagedTransport:
         self.group = group
 
     def post(self, sends, recvs):
-        torch.cuda.synchronize()  # the packed rows are on the stream
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()  # the packed rows are on the stream
         host_s = [(peer, t.detach().to("cpu").contiguous()) for peer, t in sends]
         host_r = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in recvs]
         ops = [dist.P2POp(dist.isend, h, peer, self.group) for peer, h in host_s]

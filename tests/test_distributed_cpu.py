@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 import oracle_lib as O
 from helpers import oracle_mesh
 from l3ster_amd import system
-from l3ster_amd.distributed import DistributedOperator, HaloPlan
+from l3ster_amd.distributed import DistributedOperator, HaloPlan, HostStagedTransport
 
 
 class OracleBackend:
@@ -66,7 +66,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ne, p, parts, kid, ncols, out_dir):
+def _worker(rank, world, port, ne, p, parts, kid, ncols, out_dir, staged=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -79,7 +79,7 @@ def _worker(rank, world, port, ne, p, parts, kid, ncols, out_dir):
             gid = part.node_grid_id.astype(np.float64)
             fields = np.stack([np.sin(0.37 * gid + f) for f in range(F)])
         be = OracleBackend(part, kid, p + 1, U, mask, fields=fields)
-        op = DistributedOperator(be, HaloPlan(part, U, "cpu"))
+        op = DistributedOperator(be, HaloPlan(part, U, "cpu"), transport=HostStagedTransport() if staged else None)
         n_owned = part.n_owned_nodes * U
         x_all = part.synthetic_vector(U, ncols=ncols)
         X = torch.as_tensor(x_all[:, :n_owned].copy())
@@ -92,14 +92,15 @@ def _worker(rank, world, port, ne, p, parts, kid, ncols, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ne,p,parts,kid,ncols", [
-    ((4, 2, 2), 2, (2, 1, 1), system.KERNEL_DIFFUSION3D, 1),
-    ((2, 4, 3), 3, (1, 2, 1), system.KERNEL_DIFFUSION3D, 2),
-    ((4, 4, 2), 2, (2, 2, 1), system.KERNEL_ADVDIFF3D, 1),
+@pytest.mark.parametrize("ne,p,parts,kid,ncols,staged", [
+    ((4, 2, 2), 2, (2, 1, 1), system.KERNEL_DIFFUSION3D, 1, False),
+    ((2, 4, 3), 3, (1, 2, 1), system.KERNEL_DIFFUSION3D, 2, False),
+    ((4, 4, 2), 2, (2, 2, 1), system.KERNEL_ADVDIFF3D, 1, False),
+    ((4, 2, 2), 2, (2, 1, 1), system.KERNEL_DIFFUSION3D, 2, True),  # the rehearsal transport of bench.py (host-staged messages)
 ])
-def test_distributed_apply_equals_single_rank(tmp_path, ne, p, parts, kid, ncols):
+def test_distributed_apply_equals_single_rank(tmp_path, ne, p, parts, kid, ncols, staged):
     world = int(np.prod(parts))
-    mp.spawn(_worker, args=(world, _free_port(), ne, p, parts, kid, ncols, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ne, p, parts, kid, ncols, str(tmp_path), staged), nprocs=world, join=True)
     info = system.kernel_info(kid)
     U, F = info["n_unknowns"], info["n_fields"]
     whole = system.CubePartition(ne, p, perturb=0.1)
