@@ -32,10 +32,11 @@ PARTS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # executed FP64 flops per element of sumfactFastKernel<Diffusion3D> (ISA count: (fma + fmac) * 2 + mul + add, times the
 # active lanes per element): order 6: 4 460 lane-flops x 49 lanes
 FP64_FLOP_PER_ELEM = {6: 4460 * 49}
-# executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u): per workgroup 7
-# iterations (one bx' each) of stage 1: 7 pairs x 49 x 112, stage 2: 343 rows x 441, stage 3 (factorised, second step with the
-# even-odd decomposition: 392 + 7 * 124 = 1 260 flops per row = 630 FMA equivalents): 343 rows x 630, + G
-SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * 10 * (7 * (7 * 49 * 112 + 343 * 441 + 343 * 630) + 343 * 16 * 7)
+# executed flops per element of assembleSumfactKernel at order 6, U = 4 (10 unknown pairs u' <= u), per workgroup and iteration
+# stage 1: 7 pairs x 49 x 112 FMAs, stage 2: 441 per row, stage 3 (factorised, second step with the even-odd decomposition:
+# 392 + 7 * 124 = 1 260 flops per row = 630 FMA equivalents), + G once.  The 6 off-diagonal blocks: 7 iterations of 343 rows;
+# the 4 diagonal blocks form one half (x-major) in 4 iterations of 322 + 3 x 301 rows (device/assemble.hpp, BLOCKS == 1)
+SUMFACT_ASSEMBLY_FLOP_PER_ELEM = 2 * (6 * (7 * 343 * (112 + 441 + 630) + 343 * 16 * 7) + 4 * (4 * 343 * 112 + (322 + 3 * 301) * (441 + 630) + 343 * 16 * 7))
 
 
 def algorithmic_bytes_per_dof(p, U, F=0):
@@ -280,7 +281,7 @@ def main():
         if world == 1 and op is None and p == 6:
             # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly, order 6, streaming mode
             # (checksums instead of 15 MB per matrix); outside the timed region.  Default algorithm: sum-factorised assembly
-            # (device/assemble.hpp: ~58 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
+            # (device/assemble.hpp: ~47 MFLOP per element on the vector pipe); beside it the dense K_e = (W Z)^T Z product on
             # the FP64 matrix cores (4 523 MFLOP per element using symmetry), the formulation the reference computes
             # sum-factorised kernel: the FULL sweep over the benchmark mesh (args.ne^3 elements; 262 144 at 64^3), in batches
             # of 2048; the dense product (28x slower) on three batches of 512 of the same mesh

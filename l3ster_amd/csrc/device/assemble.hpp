@@ -390,14 +390,17 @@ __device__ __forceinline__ int opaqueOffset(int x)
 // a row reader finds runs of n^2 doubles), stored as [u][u'][bx'][bz][bx][by][by'][bz'] -- row node b = (bx, by, bz), column node
 // b' = (bx', by', bz').  In the row-major layout of the reference every 64-byte line of K_e collects its 8 entries from four
 // workgroups and two iterations: measured write traffic 3.9 x the matrix (profiles/r03_tcc_assembly_stored.txt).
-template < typename K, int P, int NQ, bool TILED = false >
+// BLOCKS: 0 every pair u' <= u of unknowns (TILED: every pair), 1 the diagonal blocks u' == u only, 2 the off-diagonal ones only --
+// as kernels of their own the two kinds of iteration below get a register allocation each (both in one kernel: 302 k matrices/s at
+// order 6; separately 1.04 + 2.22 us per element of which 0.5 counted twice)
+template < typename K, int P, int NQ, bool TILED = false, int BLOCKS = 0 >
 __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
                                                                                        int64_t elem0, int xcd_group)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = SfAsmCfg< P, NQ >;
-    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, PAIRS = C::PAIRS, ROWS = C::ROWS, AROW = C::AROW;
+    constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, ROWS = C::ROWS, AROW = C::AROW;
     constexpr int         NT = C::threads, ND = N1 * N2 * U;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
@@ -414,7 +417,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     // workgroups of ONE element have the same index modulo 8, i.e. sit on one XCD and share its L2 -- in stored mode every
     // 64-byte line of K_e receives its 8 entries from 4 pair-workgroups (the unknown u' is the fastest index of a row), so
     // they should at least meet in one L2.  Otherwise blockIdx = pair + NP * element.
-    constexpr int NP = TILED ? U * U : U * (U + 1) / 2;
+    static_assert(!TILED || BLOCKS == 0);
+    constexpr int NP = TILED ? U * U : (BLOCKS == 1 ? U : (BLOCKS == 2 ? U * (U - 1) / 2 : U * (U + 1) / 2));
     int64_t       el;
     int           rem;
     if (xcd_group)
@@ -436,6 +440,17 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     {
         u   = rem / U;
         rem = rem - u * U;
+    }
+    else if constexpr (BLOCKS == 1)
+        u = rem;
+    else if constexpr (BLOCKS == 2)
+    {
+        u = 1;
+        while (rem >= u)
+        {
+            rem -= u;
+            ++u;
+        }
     }
     else
         while (rem > u)
@@ -482,26 +497,99 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     }
     __syncthreads();
 
-    // this thread's row (bx = pp, by, by') and its rows of the y product tables
-    const bool has_row = tid < ROWS;
+    // An iteration works on N1 SLOTS, each an index pair (bx, bx'), and on rows (slot, by, by').
+    // Off-diagonal blocks (and TILED, and all blocks of the one-launch kernel): iteration j holds the pairs (bx = slot, bx' = j);
+    // this thread's row is fixed.
+    // The diagonal-block kernel (BLOCKS == 1): diagonal blocks (u' == u) are symmetric in (b, b'): only the half "bx' < bx, or bx' == bx and (by' < by, or by' == by and
+    // bz' <= bz)" is formed and mirrored -- x-major, because then whole (bx, bx') pairs drop out: bx' = j needs the N1 - j pairs
+    // bx >= j, so bx' = j and bx' = N1 - j share one iteration of N1 slots (slot s < N1 - j: (j + s, j), else (s, N1 - j)), and a
+    // slot with bx == bx' has rows by' <= by only: N1 / 2 + 1 iterations instead of N1 (order 6: 4 instead of 7, of 322 and
+    // 3 x 301 rows), with a per-iteration assignment of the threads to rows.
+    constexpr int NTRI    = N1 * (N1 + 1) / 2; // rows (by' <= by) of a slot with bx == bx'
     // (TILED: by' runs fastest over the threads, so that consecutive threads write consecutive column nodes of one row node)
-    const int  row = has_row ? tid : 0, pp = row / N2, bbt = row - pp * N2, by = TILED ? bbt / N1 : bbt % N1, byp = TILED ? bbt % N1 : bbt / N1;
-    const int  bb  = by + N1 * byp; // pair index of the y product tables
+    const int  row = tid < ROWS ? tid : 0;
 
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
 
-    for (int bxp = 0; bxp < N1; ++bxp)
+    // (DIAG: the diagonal-block kernel, BLOCKS == 1)
+    auto iterations = [&]< bool DIAG >() {
+    for (int iter = 0; iter < (DIAG ? N1 / 2 + 1 : N1); ++iter)
     {
-        const int pair0 = bxp * N1; // pairs (bx, bx') = bx + N1 bx', bx = 0 .. N1-1
+        // the second list of a diagonal block's iteration: slots s >= N1 - iter hold (s, N1 - iter)
+        const bool two_lists = DIAG && iter >= 1 && iter < N1 - iter;
+        const int  split     = DIAG ? N1 - iter : N1;                    // slots below: first list
+        const int  n_slots   = DIAG && !two_lists ? N1 - iter : N1;      // (the middle bx' of an even N1 stands alone)
+        auto       slotPair  = [&](int s_, int& bx_, int& bxp_) {
+            if (!DIAG)
+            {
+                bx_  = s_;
+                bxp_ = iter;
+            }
+            else if (s_ < split)
+            {
+                bx_  = iter + s_;
+                bxp_ = iter;
+            }
+            else
+            {
+                bx_  = s_;
+                bxp_ = N1 - iter;
+            }
+        };
+        // this thread's row of the iteration: (slot pp, by, by'), its pair (bx, bx') and its rows of the y product tables
+        bool has_row;
+        int  pp, by, byp;
+        if (!DIAG)
+        {
+            has_row       = tid < ROWS;
+            pp            = row / N2;
+            const int bbt = row - pp * N2;
+            by            = TILED ? bbt / N1 : bbt % N1;
+            byp           = TILED ? bbt % N1 : bbt / N1;
+        }
+        else
+        {
+            // rows in the order: the triangle of slot 0, the triangle of slot `split` (second list), the other slots in full
+            const int n_tri = two_lists ? 2 * NTRI : NTRI;
+            int       t     = tid;
+            if (t < n_tri)
+            {
+                pp = t < NTRI ? 0 : split;
+                t  = t < NTRI ? t : t - NTRI;
+                by = 0;
+                while (t > by) // triangle index -> (by, by' <= by)
+                {
+                    t -= by + 1;
+                    ++by;
+                }
+                byp     = t;
+                has_row = true;
+            }
+            else
+            {
+                t -= n_tri;
+                const int f = t / N2, bbt = t - f * N2; // f-th slot among those with bx != bx'
+                pp          = f + 1 + (two_lists && f + 1 >= split ? 1 : 0);
+                by          = bbt % N1;
+                byp         = bbt / N1;
+                has_row     = pp < n_slots;
+                pp          = has_row ? pp : 0;
+            }
+        }
+        int bx_row, bxp;
+        slotPair(pp, bx_row, bxp);
+        const int bb = by + N1 * byp; // pair index of the y product tables
         // ---- stage 1: A[bx][g][qz][qy] for the pairs (bx, bx' = bxp): one thread per (bx, qy, qz) forms all nine groups from its
         // 16 x nq entries of G and the 4 x nq entries of the x product table of its pair -- one straight-line body of 16
         // independent 7-term sums with compile-time term lists (the earlier form dealt (group, bx, qy, qz) items to the
         // threads: a switch per item, the product-table row re-read per term, three to five LDS reads in flight)
-        for (int it = tid; it < PAIRS * NQ * NQ; it += NT)
+        for (int it = tid; it < n_slots * NQ * NQ; it += NT)
         {
-            const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ);
-            const int pair = pair0 + bx;
+            const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ); // (bx: the slot)
+            int       bx1, bx1p;
+            slotPair(bx, bx1, bx1p);
+            const int pair = bx1p * N1 + bx1; // pair index (bx, bx') = bx + N1 bx' of the x product table
             double    pxv[4][NQ];
 #pragma unroll
             for (int tx = 0; tx < 4; ++tx)
@@ -567,14 +655,20 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                     B[tz][qz] = acc;
                 }
             // ---- stage 3: M[row][(bz,bz')] = sum_{tz,qz} B[tz][qz] Pz[(bz,bz')][(tz,qz)], the table through scalar loads
-            const int rowb = pp + N1 * by, rowbp = bxp + N1 * byp;
-            // Output bookkeeping hoisted out of the entry loops: b - b' = (rowb - rowbp) + N2 (bz - bz') has the sign of bz - bz'
-            // unless they are equal, and the checksum weight 1 + (31 gi + 17 gj) mod 7 = 1 + 3 (gi + gj) mod 7 does not depend
+            const int rowb = bx_row + N1 * by, rowbp = bxp + N1 * byp;
+            // Output bookkeeping hoisted out of the entry loops: which half of a diagonal block an entry belongs to is decided by
+            // the row (rdlt) unless bx' == bx and by' == by, and the checksum weight 1 + (31 gi + 17 gj) mod 7 = 1 + 3 (gi + gj) mod 7 does not depend
             // on (bz, bz') when N2 U is a multiple of 7 (order 6: 196): three partial sums per row instead of ~15 integer
             // instructions per entry.  All loops are unrolled: (bz, bz') are compile-time and the scalar loads are issued ahead
             // of their use.  (History at order 6: per-entry bookkeeping + rolled columns 162 k matrices/s -> unrolled, hoisted
             // 193 k -> factorised 218 k.)
             constexpr bool wgt_const = (N2 * U) % 7 == 0;
+            // diagonal blocks: > 0 the whole row belongs to the formed half, == 0 (bx' == bx, by' == by) its columns bz' <= bz do
+            const int      rdlt      = bx_row != bxp ? 1 : by - byp;
+            // BLOCKS == 0 (one launch over all pairs: the stored row-major matrices) keeps the seven iterations and the z-major
+            // half b' <= b of its diagonal blocks -- there the four workgroups that fill a 64-byte line of K_e should pass
+            // through the same b_x' at about the same time (profiles/r03_assembly_diagonal_blocks.log)
+            const bool     zhalf     = !DIAG && BLOCKS == 0 && !TILED && u == up;
             const int      dlt       = rowb - rowbp; // sign of b - b' on the bz == bz' columns
             double         s_lo = 0., s_eq = 0., s_up = 0.; // sums over the columns with bz > bz', bz == bz', bz < bz'
             // Stage 3 is sum-factorised once more: the z product table is itself a product, Pz[(bz,bz')][(s + 2 s', qz)] =
@@ -582,7 +676,6 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
             // W[bz][s'][qz] = sum_s B[s + 2 s'][qz] T_s[bz][qz]: 4 nq n + 2 nq n^2 = 882 FMAs per row instead of 4 nq n^2 = 1 372,
             // and every scalar operand of the second step (the 1-D tables through scalar loads) serves a block of ZB values of bz
             // instead of one entry -- the first form waited for its scalar loads (56 scalar registers per column)
-            const bool    diag_block = !TILED && u == up;
             constexpr int ZB = 2; // values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills)
             const __attribute__((address_space(4))) double* const tIz =
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
@@ -620,12 +713,13 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 for (int bzp = 0; bzp < N1; ++bzp)
 #pragma unroll
                     for (int bi = 0; bi < ZB; ++bi)
-                        if (b0 + bi < N1 && !(diag_block && bzp > b0 + bi)) // (diagonal blocks: b_z' > b_z is the mirror image)
+                        if (b0 + bi < N1 && !(zhalf && bzp > b0 + bi)) // (z-major half: b_z' > b_z is the mirror image)
                         {
                             const int    bz = b0 + bi;
                             const double m  = Mz[bi][bzp];
                             const int  b = rowb + N2 * bz, bp = rowbp + N2 * bzp;
-                            const bool skip = !TILED && u == up && (bz != bzp ? bzp > bz : dlt < 0); // diagonal blocks: the lower part only (mirrored)
+                            // diagonal blocks: one half only (mirrored)
+                            const bool skip = DIAG ? rdlt == 0 && bzp > bz : zhalf && (bz != bzp ? bzp > bz : dlt < 0);
                             const int  gi = b * U + u, gj = bp * U + up;
                             if constexpr (TILED)
                             {
@@ -653,14 +747,17 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
             if constexpr (!TILED && wgt_const)
             {
                 // weight of this (row, column-x) pair; entries of off-diagonal blocks stand for themselves and their mirror
-                // image, in diagonal blocks those with b' < b do, b' == b counts once, b' > b is the mirror image of a counted one
-                const double wgt  = double(1 + (3 * ((rowb + rowbp) * U + u + up)) % 7);
-                const double f_eq = dlt > 0 ? 2. : (dlt == 0 ? 1. : 0.);
-                csum += wgt * (u != up ? 2. * (s_lo + s_eq + s_up) : 2. * s_lo + f_eq * s_eq);
+                // image, in diagonal blocks those of the formed half do, b' == b counts once
+                const double wgt = double(1 + (3 * ((rowb + rowbp) * U + u + up)) % 7);
+                const double f_eq = dlt > 0 ? 2. : (dlt == 0 ? 1. : 0.); // (z-major half)
+                csum += wgt * (DIAG ? (rdlt > 0 ? 2. * (s_lo + s_eq + s_up) : 2. * s_lo + s_eq)
+                                    : (zhalf ? 2. * s_lo + f_eq * s_eq : 2. * (s_lo + s_eq + s_up)));
             }
         }
         __syncthreads(); // A is rewritten by the next iteration
     }
+    };
+    iterations.template operator()< BLOCKS == 1 >();
     if (a.checksum)
     {
         // fixed-order reduction over the workgroup, one atomic per workgroup
@@ -716,6 +813,10 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                 ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, true >),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 1 >),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 2 >),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess;
             if (!ok)
             {
@@ -737,17 +838,35 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     if constexpr (S::feasible)
         if (!dense)
         {
-            auto          ks        = a.K_tiled ? assembleSumfactKernel< K, P, NQ, true > : assembleSumfactKernel< K, P, NQ >;
-            const int     NP        = a.K_tiled ? U * U : U * (U + 1) / 2;
-            const int     xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
-            const int64_t n_blocks  = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
-            if (n_blocks > int64_t(0x7fffffff))
+            const int xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
+            auto      launch    = [&](auto ks, int NP) {
+                const int64_t n_blocks = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
+                if (n_blocks > int64_t(0x7fffffff))
+                {
+                    setError("assembly batch too large: %lld workgroups", (long long)n_blocks);
+                    return -1;
+                }
+                if (n_blocks > 0)
+                    hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(S::threads), S::lds, stream, a, cbuf,
+                                       int64_t(a.elem_begin_out), xcd_group);
+                return 0;
+            };
+            // the diagonal and the off-diagonal blocks as two launches (a register allocation each); one launch over all pairs
+            // where the workgroups of an element should meet in one L2 (stored row-major matrices) or on request
+            const bool one_launch = std::getenv("L3K_ASM_ONE_LAUNCH") != nullptr || (a.K != nullptr && std::getenv("L3K_ASM_TWO_LAUNCHES") == nullptr);
+            int        rc         = 0;
+            if (a.K_tiled)
+                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U);
+            else if (one_launch)
+                rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2);
+            else
             {
-                setError("assembly batch too large: %lld workgroups", (long long)n_blocks);
-                return -1;
+                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2);
+                if (rc == 0)
+                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U);
             }
-            hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(S::threads), S::lds, stream, a, cbuf,
-                               int64_t(a.elem_begin_out), xcd_group);
+            if (rc)
+                return rc;
         }
     if (dense)
         hipLaunchKernelGGL(kg, dim3(C::NLT, static_cast< unsigned >(a.elem_count)), dim3(256), C::lds, stream, a, cbuf,
