@@ -386,6 +386,26 @@ __device__ __forceinline__ int opaqueOffset(int x)
     asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
     return y;
 }
+// the 9 nq dot products of stage 2 in the order of their results B[tz][qz]: (tz, qz, ty) with the group g of (ty, tz)
+struct Stage2Item
+{
+    int tz, qz, ty, g;
+};
+template < int NQ >
+struct Stage2Items
+{
+    Stage2Item v[9 * NQ];
+    constexpr Stage2Items() : v{}
+    {
+        constexpr int gtab[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}}; // [ty][tz]
+        int           n          = 0;
+        for (int tz = 0; tz < 4; ++tz)
+            for (int qz = 0; qz < NQ; ++qz)
+                for (int ty = 0; ty < 4; ++ty)
+                    if (gtab[ty][tz] >= 0)
+                        v[n++] = Stage2Item{tz, qz, ty, gtab[ty][tz]};
+    }
+};
 // TILED: all U x U blocks (no symmetry: more FP64 instructions for a layout in which the stores of a wave fill contiguous memory and
 // a row reader finds runs of n^2 doubles), stored as [u][u'][bx'][bz][bx][by][by'][bz'] -- row node b = (bx, by, bz), column node
 // b' = (bx', by', bz').  In the row-major layout of the reference every 64-byte line of K_e collects its 8 entries from four
@@ -633,6 +653,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                         py[ty][qy] = pt[ty * N2 * NQ + qy];
             }
             double B[4][NQ];
+            if constexpr (!TILED)
+            {
 #pragma unroll
             for (int tz = 0; tz < 4; ++tz)
 #pragma unroll
@@ -654,6 +676,45 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                     }
                     B[tz][qz] = acc;
                 }
+            }
+            else
+            {
+                // TILED (204 registers, the stores of stage 3 in flight): the 9 nq dot products (group, qz) of nq terms as a software
+                // pipeline -- the nq entries of A of item i + 1 are requested before the FMAs of item i, and the scheduler is told to
+                // keep it that way.  Left to itself the compiler forms one dependent chain per B entry and requests each pair of
+                // operands two instructions before their FMAs.  (+7 % for the tiled store, 142 -> 152 k matrices/s at order 6; the
+                // streaming kernels at 256 registers lose 1.5 % with it: profiles/r03_assembly_stage2.log)
+                constexpr int            NIT2 = 9 * NQ;
+                constexpr Stage2Items< NQ > items{};
+                const double* const      Apos = A + pp * 9 * NQ * AROW;
+                double                   abuf[2][NQ];
+                auto                     request = [&](double (&dst)[NQ], const Stage2Item it) {
+                    const double* aq = Apos + (it.g * NQ + it.qz) * AROW;
+#pragma unroll
+                    for (int qy = 0; qy < NQ; ++qy)
+                        dst[qy] = aq[qy];
+                };
+                request(abuf[0], items.v[0]);
+#pragma unroll
+                for (int i = 0; i < NIT2; ++i)
+                {
+                    const Stage2Item it = items.v[i];
+                    if (i + 1 < NIT2)
+                        request(abuf[(i + 1) & 1], items.v[i + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (two partial sums: the chain of dependent FMAs is half as long)
+                    double acc0 = i > 0 && items.v[i > 0 ? i - 1 : 0].tz == it.tz && items.v[i > 0 ? i - 1 : 0].qz == it.qz ? B[it.tz][it.qz] : 0.;
+                    double acc1 = 0.;
+#pragma unroll
+                    for (int qy = 0; qy < NQ; ++qy)
+                        if (qy % 2 == 0)
+                            acc0 += py[it.ty][qy] * abuf[i & 1][qy];
+                        else
+                            acc1 += py[it.ty][qy] * abuf[i & 1][qy];
+                    B[it.tz][it.qz] = acc0 + acc1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             // ---- stage 3: M[row][(bz,bz')] = sum_{tz,qz} B[tz][qz] Pz[(bz,bz')][(tz,qz)], the table through scalar loads
             const int rowb = bx_row + N1 * by, rowbp = bxp + N1 * byp;
             // Output bookkeeping hoisted out of the entry loops: which half of a diagonal block an entry belongs to is decided by
