@@ -65,6 +65,43 @@ def test_local_assembly_vs_oracle(ctx, kid, ne, p, vo, R, kpar):
         assert abs(cs[e] - checksum_of(K[e])) < 1e-9 * abs(checksum_of(np.abs(K[e])))
 
 
+@pytest.mark.parametrize("kid,ne,p,vo,R,kpar", CASES + [
+    (system.KERNEL_DIFFUSION3D, 1, 5, 1, 1, [0.7, 1.3]),   # n = 6: the middle b_x' of the diagonal blocks stands alone
+    (system.KERNEL_DIFFUSION3D, 1, 6, 1, 1, [0.7, 1.3]),
+    (system.KERNEL_DIFFUSION3D, 1, 7, 1, 1, [1.0, 0.5]),   # n = 8; the dense kernel unless the sum-factorised one fits
+])
+def test_diagonal_block_kernel_vs_oracle(ctx, kid, ne, p, vo, R, kpar, monkeypatch):
+    """The streaming mode forms the diagonal blocks (u' == u) by halves in merged iterations, in a kernel of its own
+    (device/assemble.hpp, BLOCKS == 1 / 2).  L3K_ASM_TWO_LAUNCHES=1 makes the stored mode take the same two kernels: K_e entry by
+    entry against the oracle, bitwise symmetric; and the streaming checksum equals the stored matrix's."""
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(ne, p, perturb=0.15)
+    nq = system.n_qps1d(p, vo)
+    mesh = system.DeviceMesh(ctx, part, U)
+    mf = system.MatrixFreeSystem(mesh, kid, kpar, asm_opts=(vo, 0, 0), n_rhs=R)
+    fields = np.random.default_rng(2).uniform(-1, 1, (F, part.n_local_nodes)) if F else None
+    if F:
+        mf.set_fields(dev(fields))
+    monkeypatch.setenv("L3K_ASM_TWO_LAUNCHES", "1")
+    K, _, cs = mf.local_assemble(want_checksum=True)
+    monkeypatch.delenv("L3K_ASM_TWO_LAUNCHES")
+    _, _, cs_stream = mf.local_assemble(want_K=False, want_F=False, want_checksum=True)
+    K1, _, _ = mf.local_assemble()
+    torch.cuda.synchronize()
+    K, K1, cs, cs_stream = K.cpu().numpy(), K1.cpu().numpy(), cs.cpu().numpy(), cs_stream.cpu().numpy()
+    for e in range(part.n_elems):
+        nf = fields[:, part.elem_nodes[e]].T if F else None
+        K_ref, _ = O.assemble_local(kid, p, nq, R, part.elem_verts[e], nf, kpar)
+        scale = np.abs(K_ref).max()
+        assert np.abs(K[e] - K_ref).max() < 1e-12 * scale
+        assert np.abs(K1[e] - K_ref).max() < 1e-12 * scale
+        assert np.array_equal(K[e], K[e].T)
+        ref_cs = checksum_of(np.abs(K[e]))
+        assert abs(cs[e] - checksum_of(K[e])) < 1e-9 * ref_cs
+        assert abs(cs_stream[e] - checksum_of(K[e])) < 1e-9 * ref_cs
+
+
 def test_local_assembly_order6_vs_golden(ctx, golden):
     """The north-star shape (order 6, 1372 x 1372) on the reference's distorted test hex: K x, diag(K), F vs the
     independent numpy/mpmath restatement; checksum-only (streaming) mode gives the same checksum."""
