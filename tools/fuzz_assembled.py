@@ -1,9 +1,11 @@
 """Randomised sweep of the assembled path on the device: random small meshes (1..3 elements per direction, perturbed), orders
-1..4, Diffusion3D / Mass3D, random Dirichlet sides.  Checked per case: (1) l3k_assemble_global (tiled layout, two streams, small
+1..6, Diffusion3D / Mass3D, random Dirichlet sides.  Checked per case: (1) l3k_assemble_global (tiled layout, two streams, small
 random workspaces: many sub-batches) gives the CSR values of l3k_local_assemble + l3k_assembled_scatter (row-major, both scatter
 kernels) to rounding; (2) with skip_dirichlet the assembled operator applied to a random x equals the matrix-free apply on the
 free dofs (the reference's cross-path property, tests/LocalOperatorTests.cpp:3-95, at mesh level); (3) the tiled element matrices
-are the row-major ones.     python tools/fuzz_assembled.py [--seconds 120] [--seed 0]"""
+are the row-major ones; (4) the streaming mode's checksums (its two kernels: diagonal blocks by halves) are those of the stored
+matrices, and the stored mode through the same two kernels gives the same, bitwise symmetric matrices.
+    python tools/fuzz_assembled.py [--seconds 120] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -35,12 +37,12 @@ def csr_graph(part, U):
     return torch.as_tensor(G.indptr.astype(np.int64), device="cuda"), torch.as_tensor(G.indices.astype(np.int32), device="cuda"), n
 
 
-t_end, n_cases, worst = time.time() + a.seconds, 0, [0.0, 0.0, 0.0]
+t_end, n_cases, worst = time.time() + a.seconds, 0, [0.0, 0.0, 0.0, 0.0]
 t_progress = time.time() + 60.0
 while time.time() < t_end:
     kid, kpar, U = [(system.KERNEL_DIFFUSION3D, [float(rng.uniform(0.5, 2)), 1.0], 4), (system.KERNEL_MASS3D, None, 2)][int(rng.integers(0, 2))]
-    p = int(rng.integers(1, 5)) if kid == system.KERNEL_DIFFUSION3D else 2  # (the shapes instantiated in libl3k.so)
-    ne = tuple(int(v) for v in rng.integers(1, 4 if p < 4 else 3, 3))
+    p = int(rng.choice([1, 2, 3, 4, 1, 2, 3, 4, 5, 6])) if kid == system.KERNEL_DIFFUSION3D else 2  # (the shapes instantiated in libl3k.so)
+    ne = tuple(int(v) for v in rng.integers(1, 4 if p < 4 else 3, 3)) if p < 5 else tuple(int(v) for v in rng.permutation([1, 1, int(rng.integers(1, 3))]))
     sides = [s for s in range(6) if rng.random() < 0.4]
     part = system.CubePartition(ne, p, perturb=0.15)
     mask = part.dirichlet_mask(U, sides=sides) if U == 4 else np.zeros(part.n_local_nodes * U, np.uint8)
@@ -92,8 +94,22 @@ while time.time() < t_end:
         worst[2] = max(worst[2], e4)
     else:
         e4 = 0.0
-    if not (e3 < 1e-11 and e4 < 1e-12):
-        print("FAIL", e3, e4, case)
+    # the streaming mode (diagonal blocks by halves in merged iterations, diagonal / off-diagonal blocks as two kernels): its
+    # checksums are those of the stored matrices; the stored mode through the same two kernels gives the same symmetric matrices
+    K, _, _ = mf.local_assemble(want_F=False)
+    _, _, cs = mf.local_assemble(want_K=False, want_F=False, want_checksum=True)
+    os.environ["L3K_ASM_TWO_LAUNCHES"] = "1"
+    K2l, _, _ = mf.local_assemble(want_F=False)
+    os.environ.pop("L3K_ASM_TWO_LAUNCHES")
+    ii = torch.arange(Nd, device="cuda")
+    wgt = (1 + (ii[:, None] * 31 + ii[None, :] * 17) % 7).double()
+    cs_ref, cs_abs = (K * wgt).sum(dim=(1, 2)), (K.abs() * wgt).sum(dim=(1, 2))
+    e5 = float(((cs - cs_ref).abs() / cs_abs).max())
+    e6 = float((K2l - K).abs().max() / K.abs().max())
+    sym = bool((K2l == K2l.transpose(1, 2)).all())
+    worst[3] = max(worst[3], e5, e6)
+    if not (e3 < 1e-11 and e4 < 1e-12 and e5 < 1e-12 and e6 < 1e-12 and sym):
+        print("FAIL", e3, e4, e5, e6, sym, case)
         sys.exit(1)
     n_cases += 1
     if time.time() > t_progress:
@@ -101,4 +117,4 @@ while time.time() < t_end:
         t_progress = time.time() + 60.0
     del mf
 print(f"{n_cases} cases; worst: routes differ by {worst[0]:.2e} (relative to |values|_max), assembled vs matrix-free {worst[1]:.2e}, "
-      f"tiled vs row-major {worst[2]:.2e}")
+      f"tiled vs row-major {worst[2]:.2e}, streaming checksums / two-kernel stored matrices vs the stored matrices {worst[3]:.2e}")
