@@ -18,6 +18,8 @@
 #include "sumfact_apply.hpp"
 
 #include <mutex>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace l3k::dev
@@ -322,6 +324,11 @@ struct SfAsmCfg
     // G | P | A
     static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * AROW);
     static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
+    // DPP2 (the streaming kernels at order 6): the rows of a slot sit in whole 16-lane DPP rows (a slot's A entries are operands
+    // of stage 2 by row broadcast), 4 per slot: (N2 + 15) / 16 * 16 lanes per slot instead of N2
+    static constexpr bool dpp2(bool tiled, int blocks) { return !tiled && blocks != 0 && P == 6; }
+    static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
+    static constexpr int  threadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
 };
 
 // Stage 1 is cooperative (A[bx][group][qz][qy] for the iteration's bx', through LDS); stages 2 and 3 are fused per row:
@@ -380,6 +387,70 @@ __device__ __forceinline__ void sweepEOScalar(const double (&in)[NIN], double (&
         out[HO] = ACC ? out[HO] + m : m;
     }
 }
+// ---- wave-uniform table operands without scalar loads: a table lives in the lanes of every 16-lane DPP row (lane j of a row holds
+// entries 16 c + j of chunk c), and an FP64 FMA takes entry T as "row_newbcast:(T % 16)" of chunk T / 16 -- v_fmac_f64_dpp at the
+// rate of the plain instruction (tools/dpp_f64_probe.hip, profiles/r03_dpp_f64_probe.log).  Conditions, checked there: the source
+// lane must be active (EXEC), so the code around these runs with whole rows of lanes; a VALU write of the table register needs two
+// wait states before the DPP read (the tables are loaded once, by memory instructions; tools/check_dpp_hazards.py scans the ISA).
+template < int T, int NCH >
+__device__ __forceinline__ void fmaTab(double& acc, const double (&tab)[NCH], double v)
+{
+    static_assert(T >= 0 && T < 16 * NCH);
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab[T / 16]), "v"(v), "n"(T % 16));
+}
+template < int... I, typename F >
+__device__ __forceinline__ void staticForImpl(std::integer_sequence< int, I... >, F&& f)
+{
+    (f(std::integral_constant< int, I >{}), ...);
+}
+template < int N, typename F >
+__device__ __forceinline__ void staticFor(F&& f)
+{
+    staticForImpl(std::make_integer_sequence< int, N >{}, static_cast< F&& >(f));
+}
+// sweepEOScalar with the even-odd tables We | Wo in DPP rows.  The first term of every sum is a plain product with a scalar operand
+// (there is no v_mul_f64 with DPP, and a zeroed accumulator costs a move per sum): first[q] = We[0][q], q = 0 .. RO-1, and
+// first[RO] = Wo[0][HO] -- RO + 1 values per table, loaded once per kernel
+template < int NIN, int NOUT, bool ANTI, bool ACC, int NCH >
+__device__ __forceinline__ void sweepEODpp(const double (&in)[NIN], double (&out)[NOUT], const double (&tab)[NCH],
+                                           const double (&first)[(NOUT + 1) / 2 + 1])
+{
+    constexpr int HI = NIN / 2, HO = NOUT / 2, RI = (NIN + 1) / 2, RO = (NOUT + 1) / 2, WO = RI * RO;
+    double        e[RI], o[HI > 0 ? HI : 1];
+#pragma unroll
+    for (int r = 0; r < HI; ++r)
+    {
+        e[r] = in[r] + in[NIN - 1 - r];
+        o[r] = in[r] - in[NIN - 1 - r];
+    }
+    if constexpr (NIN % 2)
+        e[HI] = in[HI];
+    staticFor< HO >([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        double        A = e[0] * first[q];
+        staticFor< RI - 1 >([&](auto rc) { fmaTab< (decltype(rc)::value + 1) * RO + q >(A, tab, e[decltype(rc)::value + 1]); });
+        double lo = A;
+        staticFor< HI >([&](auto rc) { fmaTab< WO + decltype(rc)::value * RO + q >(lo, tab, o[decltype(rc)::value]); });
+        const double hi   = ANTI ? lo - 2. * A : 2. * A - lo;
+        out[q]            = ACC ? out[q] + lo : lo;
+        out[NOUT - 1 - q] = ACC ? out[NOUT - 1 - q] + hi : hi;
+    });
+    if constexpr (NOUT % 2)
+    {
+        double m;
+        if constexpr (ANTI)
+        {
+            m = o[0] * first[RO];
+            staticFor< HI - 1 >([&](auto rc) { fmaTab< WO + (decltype(rc)::value + 1) * RO + HO >(m, tab, o[decltype(rc)::value + 1]); });
+        }
+        else
+        {
+            m = e[0] * first[HO];
+            staticFor< RI - 1 >([&](auto rc) { fmaTab< (decltype(rc)::value + 1) * RO + HO >(m, tab, e[decltype(rc)::value + 1]); });
+        }
+        out[HO] = ACC ? out[HO] + m : m;
+    }
+}
 __device__ __forceinline__ int opaqueOffset(int x)
 {
     int y;
@@ -414,14 +485,14 @@ struct Stage2Items
 // as kernels of their own the two kinds of iteration below get a register allocation each (both in one kernel: 302 k matrices/s at
 // order 6; separately 1.04 + 2.22 us per element of which 0.5 counted twice)
 template < typename K, int P, int NQ, bool TILED = false, int BLOCKS = 0 >
-__global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
+__global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
                                                                                        int64_t elem0, int xcd_group)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = SfAsmCfg< P, NQ >;
     constexpr int         N1 = C::N1, N2 = C::N2, NQP = C::NQP, ROWS = C::ROWS, AROW = C::AROW;
-    constexpr int         NT = C::threads, ND = N1 * N2 * U;
+    constexpr int         NT = C::threadsFor(TILED, BLOCKS), ND = N1 * N2 * U;
     constexpr int         CS = coeffStride< K >();
     constexpr TableLayout TL{N1, NQ};
     // the 16 terms (k, k') by group: type of a direction = s + 2 s' with s = (k == d + 1), s' = (k' == d + 1); groups (ty, tz):
@@ -532,6 +603,47 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
 
+    // DPPT: the 1-D tables of stage 3 (I, D and the even-odd tables of I^T, D^T) as DPP-row operands instead of scalar loads
+    constexpr bool DPPT  = C::dpp2(TILED, BLOCKS);
+    constexpr bool DPP2  = DPPT; // stage 2 with the slot's A entries as DPP-row operands (needs the unit layout of the rows)
+    constexpr int  NCH_T = (N1 * NQ + 15) / 16, EO_N = ((NQ + 1) / 2 + NQ / 2) * ((N1 + 1) / 2), NCH_E = (EO_N + 15) / 16;
+    [[maybe_unused]] double tabD[NCH_T], tabEI[NCH_E], tabED[NCH_E];
+    [[maybe_unused]] double firstEI[(N1 + 1) / 2 + 1], firstED[(N1 + 1) / 2 + 1]; // (scalar: We[0][.] and Wo[0][middle] of the two tables)
+    if constexpr (DPPT)
+    {
+        const int j = tid & 15;
+#pragma unroll
+        for (int c = 0; c < NCH_T; ++c)
+        {
+            const int t = 16 * c + j < N1 * NQ ? 16 * c + j : N1 * NQ - 1;
+            tabD[c]     = a.tables[TL.offD() + t];
+            // (opaque: a chunk whose lanes all hold the clamped last entry is wave-uniform -- the compiler kept it in scalar
+            // registers and moved it into the vector register right in front of the DPP read: the hazard of the helpers' comment)
+            asm volatile("" : "+v"(tabD[c]));
+        }
+#pragma unroll
+        for (int c = 0; c < NCH_E; ++c)
+        {
+            const int t = 16 * c + j < EO_N ? 16 * c + j : EO_N - 1;
+            tabEI[c]    = a.tables[TL.offEoIt() + t];
+            tabED[c]    = a.tables[TL.offEoDt() + t];
+            asm volatile("" : "+v"(tabEI[c]));
+            asm volatile("" : "+v"(tabED[c]));
+        }
+        constexpr int RI_ = (NQ + 1) / 2, RO_ = (N1 + 1) / 2;
+        const __attribute__((address_space(4))) double* const sI =
+            reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offEoIt()));
+        const __attribute__((address_space(4))) double* const sD =
+            reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offEoDt()));
+#pragma unroll
+        for (int q = 0; q < RO_; ++q)
+        {
+            firstEI[q] = sI[q];
+            firstED[q] = sD[q];
+        }
+        firstEI[RO_] = sI[RI_ * RO_ + N1 / 2];
+        firstED[RO_] = sD[RI_ * RO_ + N1 / 2];
+    }
     // (DIAG: the diagonal-block kernel, BLOCKS == 1)
     auto iterations = [&]< bool DIAG >() {
     for (int iter = 0; iter < (DIAG ? N1 / 2 + 1 : N1); ++iter)
@@ -560,7 +672,41 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
         // this thread's row of the iteration: (slot pp, by, by'), its pair (bx, bx') and its rows of the y product tables
         bool has_row;
         int  pp, by, byp;
-        if (!DIAG)
+        [[maybe_unused]] int n_units_iter = 0; // DPP2: 16-lane units with rows in this iteration
+        if constexpr (DPP2)
+        {
+            // 16-lane units: a slot with bx == bx' (DIAG) has the NTRI rows by' <= by in (NTRI + 15) / 16 units, every other slot its
+            // N2 rows in UNITS units; order: the triangle of slot 0, the triangle of slot `split` (second list), the other slots
+            constexpr int UT = (NTRI + 15) / 16, UF = C::UNITS;
+            const int     unit = tid >> 4, j = tid & 15;
+            const int     n_tri_slots = !DIAG ? 0 : (two_lists ? 2 : 1);
+            n_units_iter              = n_tri_slots * UT + (n_slots - n_tri_slots) * UF;
+            if (unit < n_tri_slots * UT)
+            {
+                pp    = unit < UT ? 0 : split;
+                int t = (unit < UT ? unit : unit - UT) * 16 + j;
+                has_row = t < NTRI;
+                t       = has_row ? t : 0;
+                by      = 0;
+                while (t > by) // triangle index -> (by, by' <= by)
+                {
+                    t -= by + 1;
+                    ++by;
+                }
+                byp = t;
+            }
+            else
+            {
+                const int uu = unit - n_tri_slots * UT, f = uu / UF, r = (uu - f * UF) * 16 + j; // f-th slot among the full ones
+                pp           = !DIAG ? f : f + 1 + (two_lists && f + 1 >= split ? 1 : 0);
+                has_row      = pp < n_slots && r < N2;
+                pp           = pp < n_slots ? pp : 0;
+                const int bbt = r < N2 ? r : 0;
+                by            = bbt % N1;
+                byp           = bbt / N1;
+            }
+        }
+        else if (!DIAG)
         {
             has_row       = tid < ROWS;
             pp            = row / N2;
@@ -638,7 +784,11 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = accg[g];
         }
         __syncthreads();
-        if (has_row)
+        // (DPPT: whole waves run stages 2 and 3 -- a DPP operand comes from a lane of the row that must be active; lanes without a
+        // row work on row 0 and are masked where results leave the registers)
+        const int  n_rows_iter = !DIAG ? ROWS : (two_lists ? 2 * NTRI : NTRI) + (n_slots - (two_lists ? 2 : 1)) * N2;
+        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter : (tid & ~63) < n_rows_iter;
+        if (DPPT ? wave_rows : has_row)
         {
             // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]
             // (this row's 4 nq entries of the y product table are re-read from LDS in every iteration: held across stage 3
@@ -653,7 +803,39 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                         py[ty][qy] = pt[ty * N2 * NQ + qy];
             }
             double B[4][NQ];
-            if constexpr (!TILED)
+            if constexpr (DPP2)
+            {
+                // the slot's 9 nq^2 entries of A in chunks of 16, one entry per lane of a DPP row (64 bytes of LDS per row and chunk
+                // instead of 8 bytes per lane and FMA); chunk c + 1 is requested before the FMAs of chunk c
+                constexpr int    NA = 9 * NQ * NQ, NCA = (NA + 15) / 16;
+                const double* const Apos = A + pp * 9 * NQ * AROW + (tid & 15);
+                static_assert(AROW == NQ);
+#pragma unroll
+                for (int tz = 0; tz < 4; ++tz)
+#pragma unroll
+                    for (int qz = 0; qz < NQ; ++qz)
+                        B[tz][qz] = 0.;
+                double ach[2][1];
+                ach[0][0] = Apos[0];
+                staticFor< NCA >([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c + 1 < NCA)
+                    {
+                        // (the last chunk is short: its lanes beyond the array read the array's last entries again)
+                        constexpr int last = NA - 16 * (c + 1); // entries in chunk c + 1
+                        ach[(c + 1) & 1][0] = last >= 16 ? Apos[16 * (c + 1)] : Apos[(tid & 15) < last ? 16 * (c + 1) : NA - 16];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    staticFor< (NA - 16 * c < 16 ? NA - 16 * c : 16) >([&](auto kc) {
+                        constexpr int f = 16 * c + decltype(kc)::value, g = f / (NQ * NQ), qz = (f / NQ) % NQ, qy = f % NQ;
+                        // group -> (ty, tz): 0 (II,II) 1 (DI,II) 2 (ID,II) 3 (DD,II) 4 (II,DI) 5 (II,ID) 6 (II,DD) 7 (DI,ID) 8 (ID,DI)
+                        constexpr int tyg[9] = {0, 1, 2, 3, 0, 0, 0, 1, 2}, tzg[9] = {0, 0, 0, 0, 1, 2, 3, 2, 1};
+                        fmaTab< decltype(kc)::value >(B[tzg[g]][qz], ach[c & 1], py[tyg[g]][qy]);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            else if constexpr (!TILED)
             {
 #pragma unroll
             for (int tz = 0; tz < 4; ++tz)
@@ -758,8 +940,25 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                         for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
                             for (int qz = 0; qz < NQ; ++qz)
-                                W[bi][sp][qz] = B[2 * sp][qz] * tIz[(b0 + bi) * NQ + qz] + B[2 * sp + 1][qz] * tDz[(b0 + bi) * NQ + qz];
+                                if constexpr (!DPPT)
+                                    W[bi][sp][qz] = B[2 * sp][qz] * tIz[(b0 + bi) * NQ + qz] + B[2 * sp + 1][qz] * tDz[(b0 + bi) * NQ + qz];
                     }
+                if constexpr (DPPT)
+                    staticFor< ZB >([&](auto bic) {
+                        constexpr int bi = decltype(bic)::value;
+                        // (b0 is the unrolled loop's variable, not a constant expression: one copy of the block per value)
+                        staticFor< (N1 + ZB - 1) / ZB >([&](auto blk) {
+                            constexpr int bz = decltype(blk)::value * ZB + bi;
+                            if constexpr (bz < N1)
+                                if (b0 == decltype(blk)::value * ZB)
+                                    staticFor< 2 * NQ >([&](auto ic) {
+                                        constexpr int sp = decltype(ic)::value / NQ, qz = decltype(ic)::value % NQ;
+                                        double        w  = B[2 * sp][qz] * tIz[bz * NQ + qz]; // (scalar operand: no product with DPP)
+                                        fmaTab< bz * NQ + qz >(w, tabD, B[2 * sp + 1][qz]);
+                                        W[bi][sp][qz] = w;
+                                    });
+                        });
+                    });
                 // second step with the even-odd decomposition of the two 1-D tables (I^T symmetric, D^T antisymmetric): 2 x 34
                 // instead of 2 nq n = 98 instructions per b_z, half as many scalar operands
                 double Mz[ZB][N1];
@@ -767,8 +966,16 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 for (int bi = 0; bi < ZB; ++bi)
                     if (b0 + bi < N1)
                     {
-                        sweepEOScalar< NQ, N1, false, false >(W[bi][0], Mz[bi], eoItz);
-                        sweepEOScalar< NQ, N1, true, true >(W[bi][1], Mz[bi], eoDtz);
+                        if constexpr (DPPT)
+                        {
+                            sweepEODpp< NQ, N1, false, false >(W[bi][0], Mz[bi], tabEI, firstEI);
+                            sweepEODpp< NQ, N1, true, true >(W[bi][1], Mz[bi], tabED, firstED);
+                        }
+                        else
+                        {
+                            sweepEOScalar< NQ, N1, false, false >(W[bi][0], Mz[bi], eoItz);
+                            sweepEOScalar< NQ, N1, true, true >(W[bi][1], Mz[bi], eoDtz);
+                        }
                     }
 #pragma unroll
                 for (int bzp = 0; bzp < N1; ++bzp)
@@ -787,7 +994,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                                 constexpr int64_t NNc = int64_t(N1) * N2;
                                 Kel[(u * U + up) * NNc * NNc + ((int64_t(bxp) * N1 + bz) * ROWS + row) * N1 + bzp] = m;
                             }
-                            else if (Kel && !skip)
+                            else if (Kel && !skip && has_row)
                             {
                                 Kel[int64_t(gi) * ND + gj] = m;
                                 if (gi != gj)
@@ -801,7 +1008,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                                 s_eq += bz == bzp ? m : 0.;
                                 s_up += bz < bzp ? m : 0.;
                             }
-                            else if (!skip)
+                            else if (!skip && has_row)
                                 csum += (gi != gj ? 2. : 1.) * double(1 + (gi * 31 + gj * 17) % 7) * m;
                         }
             }
@@ -811,8 +1018,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threads)) void assembleSumfactK
                 // image, in diagonal blocks those of the formed half do, b' == b counts once
                 const double wgt = double(1 + (3 * ((rowb + rowbp) * U + u + up)) % 7);
                 const double f_eq = dlt > 0 ? 2. : (dlt == 0 ? 1. : 0.); // (z-major half)
-                csum += wgt * (DIAG ? (rdlt > 0 ? 2. * (s_lo + s_eq + s_up) : 2. * s_lo + s_eq)
-                                    : (zhalf ? 2. * s_lo + f_eq * s_eq : 2. * (s_lo + s_eq + s_up)));
+                csum += (has_row ? wgt : 0.) * (DIAG ? (rdlt > 0 ? 2. * (s_lo + s_eq + s_up) : 2. * s_lo + s_eq)
+                                                     : (zhalf ? 2. * s_lo + f_eq * s_eq : 2. * (s_lo + s_eq + s_up)));
             }
         }
         __syncthreads(); // A is rewritten by the next iteration
@@ -900,7 +1107,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         if (!dense)
         {
             const int xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
-            auto      launch    = [&](auto ks, int NP) {
+            auto      launch    = [&](auto ks, int NP, int threads) {
                 const int64_t n_blocks = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
                 if (n_blocks > int64_t(0x7fffffff))
                 {
@@ -908,7 +1115,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                     return -1;
                 }
                 if (n_blocks > 0)
-                    hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(S::threads), S::lds, stream, a, cbuf,
+                    hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(threads), S::lds, stream, a, cbuf,
                                        int64_t(a.elem_begin_out), xcd_group);
                 return 0;
             };
@@ -917,14 +1124,14 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
             const bool one_launch = std::getenv("L3K_ASM_ONE_LAUNCH") != nullptr || (a.K != nullptr && std::getenv("L3K_ASM_TWO_LAUNCHES") == nullptr);
             int        rc         = 0;
             if (a.K_tiled)
-                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U);
+                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U, S::threadsFor(true, 0));
             else if (one_launch)
-                rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2);
+                rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2, S::threadsFor(false, 0));
             else
             {
-                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2);
+                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2, S::threadsFor(false, 2));
                 if (rc == 0)
-                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U);
+                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U, S::threadsFor(false, 1));
             }
             if (rc)
                 return rc;
