@@ -326,7 +326,7 @@ struct SfAsmCfg
     static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
     // DPP2 (the streaming kernels at order 6): the rows of a slot sit in whole 16-lane DPP rows (a slot's A entries are operands
     // of stage 2 by row broadcast), 4 per slot: (N2 + 15) / 16 * 16 lanes per slot instead of N2
-    static constexpr bool dpp2(bool tiled, int blocks) { return !tiled && blocks != 0 && P == 6; }
+    static constexpr bool dpp2(bool tiled, int blocks) { return !tiled && blocks != 0 && P >= 4; }
     static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
     static constexpr int  threadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
 };
@@ -425,16 +425,28 @@ __device__ __forceinline__ void sweepEODpp(const double (&in)[NIN], double (&out
     }
     if constexpr (NIN % 2)
         e[HI] = in[HI];
-    staticFor< HO >([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        double        A = e[0] * first[q];
-        staticFor< RI - 1 >([&](auto rc) { fmaTab< (decltype(rc)::value + 1) * RO + q >(A, tab, e[decltype(rc)::value + 1]); });
-        double lo = A;
-        staticFor< HI >([&](auto rc) { fmaTab< WO + decltype(rc)::value * RO + q >(lo, tab, o[decltype(rc)::value]); });
-        const double hi   = ANTI ? lo - 2. * A : 2. * A - lo;
-        out[q]            = ACC ? out[q] + lo : lo;
-        out[NOUT - 1 - q] = ACC ? out[NOUT - 1 - q] + hi : hi;
+    // (the FMAs are volatile asm and stay in program order: term by term across the sums, not sum by sum -- consecutive
+    // instructions are independent)
+    double A[HO > 0 ? HO : 1], lo[HO > 0 ? HO : 1];
+#pragma unroll
+    for (int q = 0; q < HO; ++q)
+        A[q] = e[0] * first[q];
+    staticFor< RI - 1 >([&](auto rc) {
+        staticFor< HO >([&](auto qc) { fmaTab< (decltype(rc)::value + 1) * RO + decltype(qc)::value >(A[decltype(qc)::value], tab, e[decltype(rc)::value + 1]); });
     });
+#pragma unroll
+    for (int q = 0; q < HO; ++q)
+        lo[q] = A[q];
+    staticFor< HI >([&](auto rc) {
+        staticFor< HO >([&](auto qc) { fmaTab< WO + decltype(rc)::value * RO + decltype(qc)::value >(lo[decltype(qc)::value], tab, o[decltype(rc)::value]); });
+    });
+#pragma unroll
+    for (int q = 0; q < HO; ++q)
+    {
+        const double hi   = ANTI ? lo[q] - 2. * A[q] : 2. * A[q] - lo[q];
+        out[q]            = ACC ? out[q] + lo[q] : lo[q];
+        out[NOUT - 1 - q] = ACC ? out[NOUT - 1 - q] + hi : hi;
+    }
     if constexpr (NOUT % 2)
     {
         double m;
@@ -781,7 +793,10 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                 }
 #pragma unroll
             for (int g = 0; g < 9; ++g)
-                A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = accg[g];
+                if constexpr (DPP2) // [slot][qy][g][qz]: 16 consecutive entries belong to 16 different sums of stage 2
+                    A[(bx * NQ + qyz % NQ) * 9 * NQ + g * NQ + qyz / NQ] = accg[g];
+                else
+                    A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = accg[g];
         }
         __syncthreads();
         // (DPPT: whole waves run stages 2 and 3 -- a DPP operand comes from a lane of the row that must be active; lanes without a
@@ -805,7 +820,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
             double B[4][NQ];
             if constexpr (DPP2)
             {
-                // the slot's 9 nq^2 entries of A in chunks of 16, one entry per lane of a DPP row (64 bytes of LDS per row and chunk
+                // the slot's 9 nq^2 entries of A (stored [qy][g][qz] by stage 1: consecutive FMAs go to different sums) in chunks of 16, one entry per lane of a DPP row (64 bytes of LDS per row and chunk
                 // instead of 8 bytes per lane and FMA); chunk c + 1 is requested before the FMAs of chunk c
                 constexpr int    NA = 9 * NQ * NQ, NCA = (NA + 15) / 16;
                 const double* const Apos = A + pp * 9 * NQ * AROW + (tid & 15);
@@ -827,7 +842,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     staticFor< (NA - 16 * c < 16 ? NA - 16 * c : 16) >([&](auto kc) {
-                        constexpr int f = 16 * c + decltype(kc)::value, g = f / (NQ * NQ), qz = (f / NQ) % NQ, qy = f % NQ;
+                        constexpr int f = 16 * c + decltype(kc)::value, qy = f / (9 * NQ), g = (f / NQ) % 9, qz = f % NQ; // [qy][g][qz]
                         // group -> (ty, tz): 0 (II,II) 1 (DI,II) 2 (ID,II) 3 (DD,II) 4 (II,DI) 5 (II,ID) 6 (II,DD) 7 (DI,ID) 8 (ID,DI)
                         constexpr int tyg[9] = {0, 1, 2, 3, 0, 0, 0, 1, 2}, tzg[9] = {0, 0, 0, 0, 1, 2, 3, 2, 1};
                         fmaTab< decltype(kc)::value >(B[tzg[g]][qz], ach[c & 1], py[tyg[g]][qy]);
