@@ -324,9 +324,9 @@ struct SfAsmCfg
     // G | P | A
     static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * AROW);
     static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
-    // DPP2 (the streaming kernels at order 6): the rows of a slot sit in whole 16-lane DPP rows (a slot's A entries are operands
+    // DPP2 (the streaming and the tiled-store kernels at orders >= 4): the rows of a slot sit in whole 16-lane DPP rows (a slot's A entries are operands
     // of stage 2 by row broadcast), 4 per slot: (N2 + 15) / 16 * 16 lanes per slot instead of N2
-    static constexpr bool dpp2(bool tiled, int blocks) { return !tiled && blocks != 0 && P >= 4; }
+    static constexpr bool dpp2(bool tiled, int blocks) { return (tiled || blocks != 0) && P >= 4; }
     static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
     static constexpr int  threadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
 };
@@ -616,7 +616,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
 
     // DPPT: the 1-D tables of stage 3 (I, D and the even-odd tables of I^T, D^T) as DPP-row operands instead of scalar loads
-    constexpr bool DPPT  = C::dpp2(TILED, BLOCKS);
+    constexpr bool DPPT  = C::dpp2(TILED, BLOCKS); // (the one-launch kernel for the stored row-major matrices keeps the scalar tables)
     constexpr bool DPP2  = DPPT; // stage 2 with the slot's A entries as DPP-row operands (needs the unit layout of the rows)
     constexpr int  NCH_T = (N1 * NQ + 15) / 16, EO_N = ((NQ + 1) / 2 + NQ / 2) * ((N1 + 1) / 2), NCH_E = (EO_N + 15) / 16;
     [[maybe_unused]] double tabD[NCH_T], tabEI[NCH_E], tabED[NCH_E];
@@ -685,6 +685,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         bool has_row;
         int  pp, by, byp;
         [[maybe_unused]] int n_units_iter = 0; // DPP2: 16-lane units with rows in this iteration
+        [[maybe_unused]] int row_t        = row; // TILED: this thread's row (slot, by, by') in the tiled layout's order
         if constexpr (DPP2)
         {
             // 16-lane units: a slot with bx == bx' (DIAG) has the NTRI rows by' <= by in (NTRI + 15) / 16 units, every other slot its
@@ -714,8 +715,9 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                 has_row      = pp < n_slots && r < N2;
                 pp           = pp < n_slots ? pp : 0;
                 const int bbt = r < N2 ? r : 0;
-                by            = bbt % N1;
-                byp           = bbt / N1;
+                by            = TILED ? bbt / N1 : bbt % N1; // (TILED: by' runs fastest over the lanes, cf. the static rows)
+                byp           = TILED ? bbt % N1 : bbt / N1;
+                row_t         = pp * N2 + bbt;
             }
         }
         else if (!DIAG)
@@ -1007,7 +1009,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                             if constexpr (TILED)
                             {
                                 constexpr int64_t NNc = int64_t(N1) * N2;
-                                Kel[(u * U + up) * NNc * NNc + ((int64_t(bxp) * N1 + bz) * ROWS + row) * N1 + bzp] = m;
+                                if (has_row)
+                                    Kel[(u * U + up) * NNc * NNc + ((int64_t(bxp) * N1 + bz) * ROWS + row_t) * N1 + bzp] = m;
                             }
                             else if (Kel && !skip && has_row)
                             {
