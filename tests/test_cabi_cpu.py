@@ -24,6 +24,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.l3k_version() == 100
 
 
+def test_hand_written_dpp_instructions_have_no_hazards():
+    """device/assemble.hpp issues v_fmac_f64_dpp ... row_newbcast through inline asm, which the compiler's hazard recognizer does
+    not see: the ISA of the built library is scanned for the two DPP hazards of the ISA manual (a VALU write of the DPP source
+    within 2 wait states, a VALU write of EXEC within 5) -- tools/check_dpp_hazards.py."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(root, "tools", "check_dpp_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.check(os.path.join(root, "l3ster_amd", "lib", "libl3k.so"))
+    assert n > 1000, "the DPP kernels are gone from the library?"
+    assert not bad, bad[:5]
+
+
 def test_tables_match_oracle_and_golden(golden):
     g = golden("tables")
     for p in range(1, 9):
