@@ -310,8 +310,17 @@ __global__ __launch_bounds__(256, L3K_GEMM_MIN_BLOCKS) void assembleGemmKernel(c
 //     stage 3 (qz):  M[(by,by')][(bz,bz')]  = sum_{tz} sum_qz B[tz][(by,by')][qz] P[tz][(bz,bz')][qz]
 // for every (bx, bx') and every pair of unknowns: ~1e8 flop per element at order 6 instead of 4.5e9 (O(n^7) instead of
 // O(n^9) per pair of unknowns), the same K_e to rounding (another summation order).  One workgroup per (element, u' <= u);
-// only the blocks u' <= u are formed (diagonal blocks: b' <= b) and mirrored, so K_e is bitwise symmetric as the
+// only the blocks u' <= u are formed (diagonal blocks: one half) and mirrored, so K_e is bitwise symmetric as the
 // reference's (algsys/AssembleLocalSystem.hpp:176-182).
+// Variants of the one kernel template (DESIGN.md 4.4 has the measurements behind each):
+//   * BLOCKS = 0: every pair u' <= u in one launch, seven iterations b_x', diagonal blocks: the z-major half -- the stored
+//     row-major matrices (the four workgroups that fill a 64-byte line of K_e pass through the same b_x' together);
+//   * BLOCKS = 1 / 2: the diagonal / the off-diagonal blocks as kernels of their own (a register allocation each) -- the
+//     streaming mode; diagonal blocks by x-major halves in n / 2 + 1 merged iterations;
+//   * TILED: all U x U blocks into the tiled layout (coalesced stores);
+//   * orders >= 4 of the streaming and tiled kernels: wave-uniform operands by DPP row broadcast (the slot's A entries in
+//     stage 2, the 1-D tables in stage 3) instead of LDS reads and scalar loads; the rows of a slot then sit in whole
+//     16-lane units and stages 2 and 3 run on whole waves.
 template < int P, int NQ >
 struct SfAsmCfg
 {
@@ -324,13 +333,14 @@ struct SfAsmCfg
     // G | P | A
     static constexpr size_t lds = sizeof(double) * (size_t(16) * NQP + size_t(4) * N2 * NQ + size_t(PAIRS) * 9 * NQ * AROW);
     static constexpr bool feasible = lds <= 160 * 1024 && threads <= 1024;
-    // DPP2 (the streaming and the tiled-store kernels at orders >= 4): the rows of a slot sit in whole 16-lane DPP rows (a slot's A entries are operands
-    // of stage 2 by row broadcast), 4 per slot: (N2 + 15) / 16 * 16 lanes per slot instead of N2
+    // DPP2 (the streaming and the tiled-store kernels at orders >= 4): the rows of a slot sit in whole 16-lane DPP rows (a slot's
+    // A entries are operands of stage 2 by row broadcast): UNITS * 16 lanes per slot instead of N2 (order 6: 64 for 49)
     static constexpr bool dpp2(bool tiled, int blocks) { return (tiled || blocks != 0) && P >= 4; }
     static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
     static constexpr int  threadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
 };
 
+// (The scalar-operand form, kept for orders < 4 and the one-launch kernel:)
 // Stage 1 is cooperative (A[bx][group][qz][qy] for the iteration's bx', through LDS); stages 2 and 3 are fused per row:
 // the thread of row (bx, by, by') forms its 4 nq values B[tz][qz] in registers from its own rows of the y product tables (28
 // doubles re-read from LDS per iteration) and the A arrays (LDS reads shared by the 49 threads of a bx), then forms the n^2
