@@ -337,7 +337,22 @@ struct SfAsmCfg
     // A entries are operands of stage 2 by row broadcast): UNITS * 16 lanes per slot instead of N2 (order 6: 64 for 49)
     static constexpr bool dpp2(bool tiled, int blocks) { return (tiled || blocks != 0) && P >= 4; }
     static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
-    static constexpr int  threadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
+    static constexpr int  rowThreadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
+    // PRODUCER (DPP kernels at orders >= 6): one more wave forms A of the NEXT iteration (lane = (qy, qz), every entry of G read
+    // once for all slots, the 1-D tables as scalar operands) while the row waves run stages 2 and 3 of this one on the other copy
+    // of A -- stage 1 is the LDS-bound phase (G is read once per slot by the cooperative form), stages 2 and 3 the FP64-bound one,
+    // and at order 6 the eighth wave sits on the SIMD that had one: 2, 2, 2, 2
+    static constexpr size_t A_BYTES = sizeof(double) * size_t(PAIRS) * 9 * NQ * AROW;
+    static constexpr bool   producer(bool tiled, int blocks)
+    {
+#ifdef L3K_ASM_NO_PRODUCER
+        return false;
+#else
+        return dpp2(tiled, blocks) && P >= 6 && NQ * NQ <= 64 && rowThreadsFor(tiled, blocks) + 64 <= 512 && lds + A_BYTES <= 160 * 1024;
+#endif
+    }
+    static constexpr int    threadsFor(bool tiled, int blocks) { return rowThreadsFor(tiled, blocks) + (producer(tiled, blocks) ? 64 : 0); }
+    static constexpr size_t ldsFor(bool tiled, int blocks) { return lds + (producer(tiled, blocks) ? A_BYTES : 0); }
 };
 
 // (The scalar-operand form, kept for orders < 4 and the one-launch kernel:)
@@ -627,6 +642,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
 
     // DPPT: the 1-D tables of stage 3 (I, D and the even-odd tables of I^T, D^T) as DPP-row operands instead of scalar loads
     constexpr bool DPPT  = C::dpp2(TILED, BLOCKS); // (the one-launch kernel for the stored row-major matrices keeps the scalar tables)
+    constexpr bool PRODUCER    = C::producer(TILED, BLOCKS);
+    constexpr int  ROW_THREADS = C::rowThreadsFor(TILED, BLOCKS), A_D = N1 * 9 * NQ * AROW;
     constexpr bool DPP2  = DPPT; // stage 2 with the slot's A entries as DPP-row operands (needs the unit layout of the rows)
     constexpr int  NCH_T = (N1 * NQ + 15) / 16, EO_N = ((NQ + 1) / 2 + NQ / 2) * ((N1 + 1) / 2), NCH_E = (EO_N + 15) / 16;
     [[maybe_unused]] double tabD[NCH_T], tabEI[NCH_E], tabED[NCH_E];
@@ -674,23 +691,97 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         const bool two_lists = DIAG && iter >= 1 && iter < N1 - iter;
         const int  split     = DIAG ? N1 - iter : N1;                    // slots below: first list
         const int  n_slots   = DIAG && !two_lists ? N1 - iter : N1;      // (the middle bx' of an even N1 stands alone)
-        auto       slotPair  = [&](int s_, int& bx_, int& bxp_) {
+        auto       slotPairAt = [&](int it_, int s_, int& bx_, int& bxp_) { // (the pairs of iteration it_)
             if (!DIAG)
             {
                 bx_  = s_;
-                bxp_ = iter;
+                bxp_ = it_;
             }
-            else if (s_ < split)
+            else if (s_ < N1 - it_)
             {
-                bx_  = iter + s_;
-                bxp_ = iter;
+                bx_  = it_ + s_;
+                bxp_ = it_;
             }
             else
             {
                 bx_  = s_;
-                bxp_ = N1 - iter;
+                bxp_ = N1 - it_;
             }
         };
+        auto slotPair = [&](int s_, int& bx_, int& bxp_) { slotPairAt(iter, s_, bx_, bxp_); };
+        // ---- stage 1 on the producer wave, for iteration it_ into Aout: lane (qy, qz) forms A of ALL slots.  With
+        // h[term] = G[term][qx] T_s'[bx'][qx] and, per group, hI = the sum of its h with s = I, hD = ... with s = D (only the groups
+        // 0, 2, 5 have one): A[slot][g] = sum_qx I[bx][qx] hI[g] + D[bx][qx] hD[g].  A diagonal block's iteration has two bx'
+        // (the two lists): two sets of sums
+        [[maybe_unused]] auto produce = [&](int it_, double* Aout) {
+            const int qyz = tid - ROW_THREADS;
+            if (qyz >= NQ * NQ)
+                return;
+            const bool two_  = DIAG && it_ >= 1 && it_ < N1 - it_;
+            const int  nsl_  = DIAG && !two_ ? N1 - it_ : N1, spl_ = DIAG ? N1 - it_ : N1;
+            const __attribute__((address_space(4))) double* const tI =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
+            const __attribute__((address_space(4))) double* const tD =
+                reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offD()));
+            double acc[N1][9];
+#pragma unroll
+            for (int sl = 0; sl < N1; ++sl)
+#pragma unroll
+                for (int g = 0; g < 9; ++g)
+                    acc[sl][g] = 0.;
+            const double* gq   = G + qyz * NQ;
+            const int     bxpA = it_, bxpB = two_ ? N1 - it_ : it_;
+#pragma unroll
+            for (int qx = 0; qx < NQ; ++qx)
+            {
+                const double ipA = tI[bxpA * NQ + qx], dpA = tD[bxpA * NQ + qx], ipB = tI[bxpB * NQ + qx], dpB = tD[bxpB * NQ + qx];
+                double       hIA[9], hDA[9], hIB[9], hDB[9];
+#pragma unroll
+                for (int g = 0; g < 9; ++g)
+                    hIA[g] = hDA[g] = hIB[g] = hDB[g] = 0.;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int kp = 0; kp < 4; ++kp)
+                    {
+                        constexpr int gtab[4][4] = {{0, 4, 5, 6}, {1, -1, 7, -1}, {2, 8, -1, -1}, {3, -1, -1, -1}}; // [ty][tz]
+                        const int     ty = (k == 2) + 2 * (kp == 2), tz = (k == 3) + 2 * (kp == 3);
+                        const int     g  = gtab[ty][tz];
+                        const double  gv = gq[(k * 4 + kp) * NQP + qx];
+                        const double  hA = gv * (kp == 1 ? dpA : ipA);
+                        (k == 1 ? hDA[g] : hIA[g]) += hA;
+                        if (two_)
+                        {
+                            const double hB = gv * (kp == 1 ? dpB : ipB);
+                            (k == 1 ? hDB[g] : hIB[g]) += hB;
+                        }
+                    }
+#pragma unroll
+                for (int sl = 0; sl < N1; ++sl)
+                    if (sl < nsl_)
+                    {
+                        int bx_, bxp_;
+                        slotPairAt(it_, sl, bx_, bxp_);
+                        const double ib = tI[bx_ * NQ + qx], db = tD[bx_ * NQ + qx];
+                        const bool   lb = two_ && sl >= spl_; // second list
+#pragma unroll
+                        for (int g = 0; g < 9; ++g)
+                        {
+                            acc[sl][g] += ib * (lb ? hIB[g] : hIA[g]);
+                            if (g == 0 || g == 2 || g == 5)
+                                acc[sl][g] += db * (lb ? hDB[g] : hDA[g]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int sl = 0; sl < N1; ++sl)
+                if (sl < nsl_)
+#pragma unroll
+                    for (int g = 0; g < 9; ++g)
+                        Aout[(sl * NQ + qyz % NQ) * 9 * NQ + g * NQ + qyz / NQ] = acc[sl][g]; // (the DPP kernels' layout [slot][qy][g][qz])
+        };
+        const bool          is_producer = PRODUCER && tid >= ROW_THREADS;
+        const double* const Acur        = PRODUCER ? A + (iter & 1) * A_D : A;
         // this thread's row of the iteration: (slot pp, by, by'), its pair (bx, bx') and its rows of the y product tables
         bool has_row;
         int  pp, by, byp;
@@ -774,6 +865,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         // 16 x nq entries of G and the 4 x nq entries of the x product table of its pair -- one straight-line body of 16
         // independent 7-term sums with compile-time term lists (the earlier form dealt (group, bx, qy, qz) items to the
         // threads: a switch per item, the product-table row re-read per term, three to five LDS reads in flight)
+        if (!PRODUCER || iter == 0)
+        {
         for (int it = tid; it < n_slots * NQ * NQ; it += NT)
         {
             const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ); // (bx: the slot)
@@ -811,10 +904,15 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                     A[((bx * 9 + g) * NQ + qyz / NQ) * AROW + qyz % NQ] = accg[g];
         }
         __syncthreads();
+        }
+        // (A of iteration 0 by the cooperative stage 1 above, all waves: the producer alone would take as long as a whole iteration)
+        if constexpr (PRODUCER)
+            if (is_producer && iter + 1 < (DIAG ? N1 / 2 + 1 : N1))
+                produce(iter + 1, A + ((iter + 1) & 1) * A_D);
         // (DPPT: whole waves run stages 2 and 3 -- a DPP operand comes from a lane of the row that must be active; lanes without a
         // row work on row 0 and are masked where results leave the registers)
         const int  n_rows_iter = !DIAG ? ROWS : (two_lists ? 2 * NTRI : NTRI) + (n_slots - (two_lists ? 2 : 1)) * N2;
-        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter : (tid & ~63) < n_rows_iter;
+        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter && !is_producer : (tid & ~63) < n_rows_iter;
         if (DPPT ? wave_rows : has_row)
         {
             // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]
@@ -835,7 +933,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                 // the slot's 9 nq^2 entries of A (stored [qy][g][qz] by stage 1: consecutive FMAs go to different sums) in chunks of 16, one entry per lane of a DPP row (64 bytes of LDS per row and chunk
                 // instead of 8 bytes per lane and FMA); chunk c + 1 is requested before the FMAs of chunk c
                 constexpr int    NA = 9 * NQ * NQ, NCA = (NA + 15) / 16;
-                const double* const Apos = A + pp * 9 * NQ * AROW + (tid & 15);
+                const double* const Apos = Acur + pp * 9 * NQ * AROW + (tid & 15);
                 static_assert(AROW == NQ);
 #pragma unroll
                 for (int tz = 0; tz < 4; ++tz)
@@ -1108,13 +1206,13 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                       hipFuncSetAttribute(reinterpret_cast< const void* >(kg), hipFuncAttributeMaxDynamicSharedMemorySize, int(C::lds)) == hipSuccess;
             if constexpr (S::feasible)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 0))) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, true >),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(true, 0))) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 1 >),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess &&
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 1))) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 2 >),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::lds)) == hipSuccess;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 2))) == hipSuccess;
             if (!ok)
             {
                 setError("hipFuncSetAttribute failed for the assembly kernels");
@@ -1136,7 +1234,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         if (!dense)
         {
             const int xcd_group = a.K != nullptr && std::getenv("L3K_ASM_NO_XCD") == nullptr;
-            auto      launch    = [&](auto ks, int NP, int threads) {
+            auto      launch    = [&](auto ks, int NP, int threads, size_t lds_bytes) {
                 const int64_t n_blocks = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
                 if (n_blocks > int64_t(0x7fffffff))
                 {
@@ -1144,7 +1242,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
                     return -1;
                 }
                 if (n_blocks > 0)
-                    hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(threads), S::lds, stream, a, cbuf,
+                    hipLaunchKernelGGL(ks, dim3(static_cast< unsigned >(n_blocks)), dim3(threads), lds_bytes, stream, a, cbuf,
                                        int64_t(a.elem_begin_out), xcd_group);
                 return 0;
             };
@@ -1153,14 +1251,14 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
             const bool one_launch = std::getenv("L3K_ASM_ONE_LAUNCH") != nullptr || (a.K != nullptr && std::getenv("L3K_ASM_TWO_LAUNCHES") == nullptr);
             int        rc         = 0;
             if (a.K_tiled)
-                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U, S::threadsFor(true, 0));
+                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U, S::threadsFor(true, 0), S::ldsFor(true, 0));
             else if (one_launch)
-                rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2, S::threadsFor(false, 0));
+                rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2, S::threadsFor(false, 0), S::ldsFor(false, 0));
             else
             {
-                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2, S::threadsFor(false, 2));
+                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2, S::threadsFor(false, 2), S::ldsFor(false, 2));
                 if (rc == 0)
-                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U, S::threadsFor(false, 1));
+                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U, S::threadsFor(false, 1), S::ldsFor(false, 1));
             }
             if (rc)
                 return rc;
