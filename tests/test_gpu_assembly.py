@@ -69,6 +69,7 @@ def test_local_assembly_vs_oracle(ctx, kid, ne, p, vo, R, kpar):
     (system.KERNEL_DIFFUSION3D, 1, 5, 1, 1, [0.7, 1.3]),   # n = 6: the middle b_x' of the diagonal blocks stands alone
     (system.KERNEL_DIFFUSION3D, 1, 6, 1, 1, [0.7, 1.3]),
     (system.KERNEL_DIFFUSION3D, 1, 7, 1, 1, [1.0, 0.5]),   # n = 8; the dense kernel unless the sum-factorised one fits
+    (system.KERNEL_ADVDIFF3D, (2, 1, 1), 4, 1, 1, [0.7, 1.3, 0.5]),  # external fields + the DPP kernels (orders >= 4)
 ])
 def test_diagonal_block_kernel_vs_oracle(ctx, kid, ne, p, vo, R, kpar, monkeypatch):
     """The streaming mode forms the diagonal blocks (u' == u) by halves in merged iterations, in a kernel of its own
