@@ -986,7 +986,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
             }
             else
             {
-                // TILED (204 registers, the stores of stage 3 in flight): the 9 nq dot products (group, qz) of nq terms as a software
+                // TILED at orders < 4 (orders >= 4 take the DPP form above; measured at order 6 before that existed: 204 registers,
+                // the stores of stage 3 in flight): the 9 nq dot products (group, qz) of nq terms as a software
                 // pipeline -- the nq entries of A of item i + 1 are requested before the FMAs of item i, and the scheduler is told to
                 // keep it that way.  Left to itself the compiler forms one dependent chain per B entry and requests each pair of
                 // operands two instructions before their FMAs.  (+7 % for the tiled store, 142 -> 152 k matrices/s at order 6; the
