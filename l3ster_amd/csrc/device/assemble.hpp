@@ -1032,6 +1032,21 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
             // of their use.  (History at order 6: per-entry bookkeeping + rolled columns 162 k matrices/s -> unrolled, hoisted
             // 193 k -> factorised 218 k.)
             constexpr bool wgt_const = (N2 * U) % 7 == 0;
+            // Otherwise the weight depends on (bz, bz') through bz + bz' only: 1 + (c0 + step (bz + bz')) mod 7 with c0 of the row and
+            // step = 3 N2 U mod 7 -- 2 n - 1 weights per row (an add and a conditional subtract each) instead of ~15 integer
+            // instructions per entry (orders 4, 5, 7: the bookkeeping cost more than the entries)
+            [[maybe_unused]] double wt[2 * N1 - 1];
+            if constexpr (!TILED && !wgt_const)
+            {
+                constexpr int step = (3 * N2 * U) % 7;
+                const int     c0   = (3 * ((rowb + rowbp) * U + u + up)) % 7;
+#pragma unroll
+                for (int sb = 0; sb < 2 * N1 - 1; ++sb)
+                {
+                    const int v = c0 + (step * sb) % 7; // < 14
+                    wt[sb]      = double(1 + (v >= 7 ? v - 7 : v));
+                }
+            }
             // diagonal blocks: > 0 the whole row belongs to the formed half, == 0 (bx' == bx, by' == by) its columns bz' <= bz do
             const int      rdlt      = bx_row != bxp ? 1 : by - byp;
             // BLOCKS == 0 (one launch over all pairs: the stored row-major matrices) keeps the seven iterations and the z-major
@@ -1136,15 +1151,19 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                                 s_eq += bz == bzp ? m : 0.;
                                 s_up += bz < bzp ? m : 0.;
                             }
-                            else if (!skip && has_row)
-                                csum += (gi != gj ? 2. : 1.) * double(1 + (gi * 31 + gj * 17) % 7) * m;
+                            else
+                            {
+                                s_lo += bz > bzp ? wt[bz + bzp] * m : 0.;
+                                s_eq += bz == bzp ? wt[bz + bzp] * m : 0.;
+                                s_up += bz < bzp ? wt[bz + bzp] * m : 0.;
+                            }
                         }
             }
-            if constexpr (!TILED && wgt_const)
+            if constexpr (!TILED)
             {
-                // weight of this (row, column-x) pair; entries of off-diagonal blocks stand for themselves and their mirror
-                // image, in diagonal blocks those of the formed half do, b' == b counts once
-                const double wgt = double(1 + (3 * ((rowb + rowbp) * U + u + up)) % 7);
+                // weight of this (row, column-x) pair (already in the sums if it varies with bz + bz'); entries of off-diagonal blocks
+                // stand for themselves and their mirror image, in diagonal blocks those of the formed half do, b' == b counts once
+                const double wgt = wgt_const ? double(1 + (3 * ((rowb + rowbp) * U + u + up)) % 7) : 1.;
                 const double f_eq = dlt > 0 ? 2. : (dlt == 0 ? 1. : 0.); // (z-major half)
                 csum += (has_row ? wgt : 0.) * (DIAG ? (rdlt > 0 ? 2. * (s_lo + s_eq + s_up) : 2. * s_lo + s_eq)
                                                      : (zhalf ? 2. * s_lo + f_eq * s_eq : 2. * (s_lo + s_eq + s_up)));
