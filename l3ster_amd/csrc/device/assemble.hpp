@@ -338,7 +338,7 @@ struct SfAsmCfg
     static constexpr bool dpp2(bool tiled, int blocks) { return (tiled || blocks != 0) && P >= 4; }
     static constexpr int  UNITS = (N2 + 15) / 16; // 16-lane units per slot
     static constexpr int  rowThreadsFor(bool tiled, int blocks) { return dpp2(tiled, blocks) ? ((PAIRS * UNITS * 16 + 63) / 64) * 64 : threads; }
-    // PRODUCER (DPP kernels at orders >= 6): one more wave forms A of the NEXT iteration (lane = (qy, qz), every entry of G read
+    // PRODUCER (DPP kernels at orders 5 and 6; order 4: slower, order 7: a ninth wave would halve the registers): one more wave forms A of the NEXT iteration (lane = (qy, qz), every entry of G read
     // once for all slots, the 1-D tables as scalar operands) while the row waves run stages 2 and 3 of this one on the other copy
     // of A -- stage 1 is the LDS-bound phase (G is read once per slot by the cooperative form), stages 2 and 3 the FP64-bound one,
     // and at order 6 the eighth wave sits on the SIMD that had one: 2, 2, 2, 2
@@ -348,7 +348,7 @@ struct SfAsmCfg
 #ifdef L3K_ASM_NO_PRODUCER
         return false;
 #else
-        return dpp2(tiled, blocks) && P >= 6 && NQ * NQ <= 64 && rowThreadsFor(tiled, blocks) + 64 <= 512 && lds + A_BYTES <= 160 * 1024;
+        return dpp2(tiled, blocks) && P >= 5 && NQ * NQ <= 64 && rowThreadsFor(tiled, blocks) + 64 <= 512 && lds + A_BYTES <= 160 * 1024;
 #endif
     }
     static constexpr int    threadsFor(bool tiled, int blocks) { return rowThreadsFor(tiled, blocks) + (producer(tiled, blocks) ? 64 : 0); }
