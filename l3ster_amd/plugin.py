@@ -63,6 +63,13 @@ def compile_kernel(type_name, source, kernel_id, shapes, kind="domain", display_
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise capi.L3KError(f"kernel plugin failed to compile:\n{r.stderr[-4000:]}")
+        # the assembly kernels of a plugin carry the library's hand-written DPP instructions: the same ISA scan as for libl3k.so
+        from . import isa_check
+        if os.path.exists(isa_check.OBJDUMP):
+            _, bad = isa_check.check_dpp_hazards(so + ".tmp")
+            if bad:
+                os.unlink(so + ".tmp")
+                raise capi.L3KError(f"kernel plugin: DPP hazard in the generated code, refusing to load it: {bad[:3]}")
         os.replace(so + ".tmp", so)
         if verbose:
             print(f"[l3k plugin] built {so}")

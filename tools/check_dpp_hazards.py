@@ -1,78 +1,12 @@
-"""The hand-written DPP instructions (inline asm v_fmac_f64_dpp ... row_newbcast, device/assemble.hpp) are opaque to the compiler's
-hazard recognizer.  This scans the gfx950 ISA of a built library for the two hazards the ISA manual lists for DPP reads:
-  * a VALU instruction that writes the DPP source register (src0) needs 2 wait states before the DPP instruction,
-  * a VALU instruction that writes EXEC (v_cmpx_*, v_readlane into exec does not exist) needs 5.
-A wait state is one issued instruction; s_nop N counts N + 1.        python tools/check_dpp_hazards.py [l3ster_amd/lib/libl3k.so]
-Exit code 1 and a listing if a hazard is found.  (Run by tests/test_build.py on the CPU.)"""
+"""Scan a built library for hazards of the hand-written DPP instructions (l3ster_amd/isa_check.py has the rules).
+    python tools/check_dpp_hazards.py [l3ster_amd/lib/libl3k.so]
+Exit code 1 and a listing if a hazard is found.  (Also run by tests/test_cabi_cpu.py on the CPU and by the plugin build.)"""
 import os
-import re
-import subprocess
 import sys
-import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-import kernel_resources as kr  # noqa: E402
-
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
-
-
-def regs(tok):
-    m = REG.fullmatch(tok.strip().lstrip("-|").rstrip("|,"))
-    if not m:
-        return None
-    if m.group(3) is not None:
-        return int(m.group(3)), int(m.group(3))
-    return int(m.group(1)), int(m.group(2))
-
-
-def check(path):
-    n_dpp, bad = 0, []
-    for co in kr.code_objects(path):
-        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
-            f.write(co)
-        try:
-            text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
-        finally:
-            os.unlink(f.name)
-        func, window = "", []  # window: the last instructions as (mnemonic, written vgpr range or None, wait states)
-        for line in text.splitlines():
-            if line.endswith(">:"):
-                func, window = line.split("<", 1)[1][:-2], []
-                continue
-            body = line.split("//")[0].strip()
-            if not body or body.startswith(("/", ".")) or ":" in body.split()[0]:
-                continue
-            parts = body.split(None, 1)
-            mn, ops = parts[0], (parts[1] if len(parts) > 1 else "")
-            if "_dpp" in mn and "row_newbcast" in ops:
-                n_dpp += 1
-                toks = ops.split(",")
-                src0 = regs(toks[1].split()[0]) if len(toks) > 1 else None
-                states = 0
-                for pmn, pw, pstates in reversed(window):
-                    if pmn.startswith("v_") and src0 and pw and not (pw[1] < src0[0] or pw[0] > src0[1]) and states < 2:
-                        bad.append((func, body, f"{pmn} writes the DPP source {states} wait state(s) earlier"))
-                    if pmn.startswith("v_cmpx") and states < 5:
-                        bad.append((func, body, f"{pmn} writes EXEC {states} wait state(s) earlier"))
-                    states += pstates
-                    if states >= 5:
-                        break
-            wr = None
-            if mn.startswith("v_") and ops:
-                wr = regs(ops.split(",")[0].split()[0])
-            st = 1
-            if mn == "s_nop":
-                try:
-                    st = int(ops.strip(), 0) + 1
-                except ValueError:
-                    st = 1
-            window.append((mn, wr, st))
-            if len(window) > 8:
-                window.pop(0)
-    return n_dpp, bad
-
+sys.path.insert(0, ROOT)
+from l3ster_amd.isa_check import check_dpp_hazards as check  # noqa: E402
 
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "l3ster_amd", "lib", "libl3k.so")
