@@ -8,7 +8,6 @@
 #include "../user_kernels.hpp"
 #include "sumfact_apply.hpp"
 #include "sumfact_fast.hpp"
-#include "sumfact_plane.hpp"
 #include "diag.hpp"
 #include "assemble.hpp"
 #include "boundary.hpp"

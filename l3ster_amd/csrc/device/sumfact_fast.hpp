@@ -1187,11 +1187,6 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #endif
 }
 
-template < typename K, int P, int NQ >
-struct PlaneCfg;
-template < typename K, int P, int NQ >
-int launchSumfactPlane(const ElemArgs& a, const void* kparam_blob, hipStream_t stream);
-
 template < typename K, int P, int NQ, bool MULTI >
 int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
 {
@@ -1237,10 +1232,6 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
                             (a.yg == nullptr || (a.yg == a.y + a.n_owned_dofs && (!MULTI || a.ldyg == a.ldy)));
     const bool  split    = !contiguous;
     // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
-    // round-3 experiment: the plane-streamed kernel (device/sumfact_plane.hpp) behind L3K_PLANE_KERNEL=1
-    if constexpr (!MULTI && PlaneCfg< K, P, NQ >::feasible)
-        if (!split && !a.energy && std::getenv("L3K_PLANE_KERNEL") != nullptr)
-            return launchSumfactPlane< K, P, NQ >(a, kparam_blob, stream);
     const bool  affine   = !MULTI && a.all_affine && !split && !a.energy && std::getenv("L3K_NO_AFFINE") == nullptr;
     decltype(&sumfactFastKernel< K, P, NQ, false, false >) kernel;
     if constexpr (MULTI) // (no fused energy, no affine variant: plain applies of several columns)
