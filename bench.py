@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--ne 64] [--order 6]
 
+N > 1: one process per GPU.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) this process
+is one rank; typed as above without a launcher it starts its N ranks itself as child processes and relays rank 0's JSON line.
+
 A "step" is one operator apply Y <- A X (alpha = 1, beta = 0) over the whole mesh.  Workload per GPU (weak scaling):
 a 64^3-element block of order-6 hexes on [0,1]^3 (228.3 M global dofs on one GPU; 128^3 = BASELINE.json config 3 on
 8 GPUs as 2x2x2 blocks), smoothly perturbed vertices (no affine shortcut), Dirichlet on unknown 0 of all six sides,
@@ -24,7 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from l3ster_amd import system  # noqa: E402
+from l3ster_amd import launch, system  # noqa: E402
 from l3ster_amd.distributed import DistributedOperator, HaloPlan, HostStagedTransport, NativeDistributedOperator, NativeHalo  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -128,14 +131,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    os.environ["L3K_GENERIC_BELOW"] = "0"  # small --ne runs time the kernel named in the roofline object, not the small-launch route
+    if args.gpus not in PARTS:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    if launch.needs_self_launch(args.gpus):  # typed without a launcher: this process starts the ranks and stays off the GPU
+        return launch.self_launch(__file__, sys.argv[1:], args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if args.gpus not in PARTS:
-        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
     # L3K_BENCH_REHEARSAL=1: all ranks on GPU 0 with the gloo backend -- the N > 1 code path (partition, exchange lists, split-phase
@@ -144,6 +148,8 @@ def main():
     rehearsal = os.environ.get("L3K_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        if os.environ.get("L3K_BENCH_FAIL_RANK") == str(rank):  # (test hook of the self-launcher: a rank that dies before any collective)
+            raise SystemExit(f"rank {rank}: failing on request (L3K_BENCH_FAIL_RANK)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("L3K_FORCE_DIST") == "1"  # the latter: smoke-test of the N > 1 code path at N = 1
@@ -163,6 +169,7 @@ def main():
     part = system.CubePartition(ne_global, p, parts, rank, perturb=0.1)
     mask = part.dirichlet_mask(U)
     ctx = system.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+    ctx.set_tuning(generic_below=0)  # small --ne runs time the kernel named in the roofline object, not the small-launch route
     mesh = system.DeviceMesh(ctx, part, U, mask)
     mf = system.MatrixFreeSystem(mesh, kid, [1.0, 1.0])
     n_owned = part.n_owned_nodes * U
@@ -268,16 +275,20 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": traffic_source,
-                              "kernel": "sumfactFastKernel" + (" (the three element launches of the partitioned apply, summed; per step the max over the ranks)" if op is not None else ""),
+                              # the kernel the timed launches took, as the launcher itself reports it (l3k_mf_route)
+                              "kernel": mf.route(2 if op is None else 0) + (" (the three element launches of the partitioned apply, summed; per step the max over the ranks)" if op is not None else ""),
                               "transport": None if op is None else ("l3k_mf_apply_dist (RCCL inside the library)" if native else "torch.distributed P2P"),
                               "kernel_ms": ms, "kernel_ms_mean": float(np.mean(kernel_times)), "kernel_ms_stat": "median of the timed launches",
                               "bytes_per_dof": bpd, "dofs_per_launch": launch_dofs,
                               "algorithmic_bytes_per_launch": alg_bytes,
-                              "fp64_note": "not HBM-bound (DESIGN.md 4.1): executed vector FP64 flops per element from the ISA against the "
-                                           "78.6 TFLOP/s FP64 peak (vector and matrix FP64 share one pipe on this part); the VALU, LDS "
-                                           "and atomic ceilings of this formulation sit at 0.36-0.38 of the HBM roofline",
+                              "fp64_note": "not HBM-bound (DESIGN.md 4.1): the kernel is bound by FP64 vector issue at the occupancy its "
+                                           "registers and LDS admit; fp64_frac = executed vector FP64 flops per element (ISA count) against "
+                                           "the 78.6 TFLOP/s FP64 peak (vector and matrix FP64 share one pipe on this part).  Perfect issue "
+                                           "of this instruction stream on 49 of 64 lanes would be ~0.34 of the HBM roofline; the practical "
+                                           "ceiling of one wave per element at 7-8 waves per CU is what is measured here",
                               "fp64_tflops": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12,
-                              "fp64_peak_tflops": 78.6}
+                              "fp64_peak_tflops": 78.6,
+                              "fp64_frac": None if flop_per_elem is None else flop_per_elem * n_launch_elems / (ms * 1e-3) / 1e12 / 78.6}
         if world == 1 and op is None and p == 6:
             # the second half of BASELINE.json's metric: element matrices/s of LocalAssembly, order 6, streaming mode
             # (checksums instead of 15 MB per matrix); outside the timed region.  Default algorithm: sum-factorised assembly
@@ -300,11 +311,8 @@ def main():
 
             n_sweep = part.n_elems
             rate = assembly_rate(n_sweep)
-            os.environ["L3K_ASSEMBLE_DENSE"] = "1"
-            try:
+            with ctx.tuning(assemble_dense=1):
                 rate_dense = assembly_rate(min(1536, n_sweep), 512)
-            finally:
-                os.environ.pop("L3K_ASSEMBLE_DENSE", None)
             nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * 7
             dense_flops = kd * nd * (nd + 1)          # symmetric half of 2*K*N^2
             sf_flops = SUMFACT_ASSEMBLY_FLOP_PER_ELEM  # executed by the sum-factorised kernel (order 6, U = 4, E = 7)
@@ -342,7 +350,7 @@ def main():
             dofs4 = part4.n_global_nodes * U
             result["order4_apply"] = {"workload": f"Diffusion3D matrix-free apply, hex mesh {args.ne}^3, order 4, {dofs4} dofs "
                                                   "(BASELINE.json configs[1])",
-                                      "value": dofs4 / (ms4 * 1e-3), "unit": "DOF/s", "ms_per_step": ms4,
+                                      "value": dofs4 / (ms4 * 1e-3), "unit": "DOF/s", "ms_per_step": ms4, "kernel": mf4.route(),
                                       "roofline_frac_hbm": dofs4 / (ms4 * 1e-3) * algorithmic_bytes_per_dof(p4, U) / 1e9 / HBM_PEAK_GBS}
             del mf4, X4, Y4, part4
             # the reference's own benchmark mesh is the UNIFORM cube (benchmarks/Diffusion3D: makeCubeMesh): every element is a
@@ -362,7 +370,7 @@ def main():
             torch.cuda.synchronize()
             msu = u0.elapsed_time(u1) / args.steps
             result["uniform_mesh_apply"] = {"workload": f"the same apply on the unperturbed {args.ne}^3 cube (all elements affine: the reference benchmark's mesh)",
-                                            "value": global_dofs / (msu * 1e-3), "unit": "DOF/s", "ms_per_step": msu,
+                                            "value": global_dofs / (msu * 1e-3), "unit": "DOF/s", "ms_per_step": msu, "kernel": mfu.route(),
                                             "roofline_frac_hbm_whole_apply": global_dofs / (msu * 1e-3) * bpd / 1e9 / HBM_PEAK_GBS}
             del mfu, Yu, partu
         if world == 1 and op is None:

@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define L3K_VERSION 100
+/* 101 (round 4): l3k_cg_update_xr / _update_p replaced by l3k_cg_update_z / _update_px (the iteration keeps z = M^-1 r; d_r holds z),
+ * new: l3k_ctx_set_reference_z0, l3k_ctx_get/set_tuning, l3k_mf_route */
+#define L3K_VERSION 101
 
 typedef struct l3k_ctx      l3k_ctx;
 typedef struct l3k_mesh     l3k_mesh;
@@ -106,6 +108,33 @@ int l3k_ctx_set_stream(l3k_ctx* ctx, void* hip_stream);
  * comes from the fixed-order dot product.  Boundary terms created while the mode is on colour their element sides the
  * same way and launch per colour behind the domain kernel.  Slower (one launch per colour). */
 int l3k_ctx_set_deterministic(l3k_ctx* ctx, int on);
+/* Which point a DOMAIN kernel sees in the matrix-free apply.  The reference is not consistent with itself here: its hex
+ * sum-factorisation path builds SpaceTimePoint{Point<3>{x, y, 0.}, time} (algsys/SumFactorization.hpp:732, a copy of the 2-D
+ * line :656), its local-element path -- assembleLocalSystem, evaluateLocalOperator, precomputeOperatorDiagonalAndRhs -- the
+ * true point (algsys/AssembleLocalSystem.hpp:229-230).  Default (on = 0): the true point everywhere, i.e. apply, diag / rhs
+ * and LocalAssembly describe ONE operator.  on = 1: applies launched from this context afterwards pass z = 0 like the
+ * reference's evalAtHexQPs (bit-for-bit reference behaviour for a kernel that reads point.space.z() under
+ * sum-factorisation); diag / rhs and LocalAssembly keep the true point, as in the reference.  Kernels that do not read z
+ * are unaffected. */
+int l3k_ctx_set_reference_z0(l3k_ctx* ctx, int on);
+/* Launch-route settings of a context.  The defaults are what the measurements recorded in DESIGN.md chose; the fields exist so
+ * that tests and tools can take the other route ON PURPOSE.  The environment is consulted once, in l3k_ctx_create
+ * (L3K_GENERIC_BELOW, L3K_FAST_STATIC, L3K_FAST_WAVES_PER_CU, L3K_NO_AFFINE, L3K_COLUMN_BY_COLUMN, L3K_ASSEMBLE_DENSE,
+ * L3K_ASM_TWO_LAUNCHES, L3K_SCATTER_PER_ENTRY initialise the fields below, L3K_DETERMINISTIC the deterministic mode): nothing on the
+ * launch path reads the environment, and l3k_mf_route names the kernel a launch takes. */
+typedef struct
+{
+    int64_t generic_below;         /* element launches of fewer elements take the generic LDS kernel (latency-bound sizes); 1500 */
+    int     static_deal;           /* single-wave kernel: static deal of the element batches instead of the dynamic one; 0      */
+    int     waves_per_cu;          /* single-wave kernel: persistent waves per CU, 0 = as many as LDS and registers admit; 0    */
+    int     no_affine;             /* never take the affine variant (one Jacobian per element) on all-affine meshes; 0          */
+    int     column_by_column;      /* multi-column applies as one launch per column (cross-check of the one-pass variant); 0    */
+    int     assemble_dense;        /* LocalAssembly as the dense FP64-MFMA product instead of the sum-factorised kernels; 0     */
+    int     assemble_two_launches; /* stored row-major LocalAssembly as two launches (diagonal / off-diagonal blocks); 0        */
+    int     scatter_per_entry;     /* l3k_assembled_scatter: one wave per row with a search per entry (round-2 kernel); 0       */
+} l3k_tuning;
+int l3k_ctx_get_tuning(const l3k_ctx* ctx, l3k_tuning* out);
+int l3k_ctx_set_tuning(l3k_ctx* ctx, const l3k_tuning* in);
 int l3k_ctx_synchronize(l3k_ctx* ctx);
 int l3k_ctx_destroy(l3k_ctx* ctx);
 
@@ -138,6 +167,11 @@ int l3k_mf_destroy(l3k_mf* mf);
  * (post::FieldAccess, post/FieldAccess.hpp:21-30).  The pointer is kept, not copied. */
 int l3k_mf_set_fields(l3k_mf* mf, const double* d_soa, size_t ld);
 int l3k_mf_set_time(l3k_mf* mf, double time);
+/* Which kernel would l3k_mf_apply_elems(mf, which, ..., ncols, ...) launch for its elements right now?  Writes a one-line
+ * description into buf (NUL-terminated, truncated to n bytes): kernel template and variant, lanes, LDS, waves per CU, grid --
+ * decided by the same code as the launch itself.  For run-time reports (bench.py prints it) and for tests that assert a route.
+ * with_energy != 0: as inside l3k_mf_apply_energy / between l3k_mf_energy_begin and _end. */
+int l3k_mf_route(l3k_mf* mf, int which, int ncols, int with_energy, char* buf, size_t n);
 
 /* Y <- alpha*A*X + beta*Y.  Operator::apply / applyImpl, algsys/MatrixFreeSystem.hpp:34-41,1020-1140, for a rank
  * without ghosts (n_ghost_nodes == 0): scale (:1038), gather with Dirichlet -> 0 (:421-467), sum-factorised element
@@ -244,14 +278,14 @@ int l3k_average_values(l3k_ctx* ctx, const double* d_sum, const double* d_count,
  *                        residual_scaling 0 none / 1 initial residual / 2 norm of b (IterSolverOpts,
  *                        solve/SolverInterface.hpp:26-37); check_every = iterations between convergence checks (each is
  *                        one 32-byte device-to-host copy)
- *   l3k_cg_*           : the fused vector kernels of one iteration for partitioned vectors: the caller all-reduces the
- *                        device scalar block s[8] (0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>) between them:
- *                          init:      r <- b - r (r = A x0 on entry), p <- minv r, s[2] = s[0] = <r,p>, s[3] = <r,r>
- *                          dot_pAp:   s[1] = <p, Ap>
- *                          update_xr: alpha = s[0]/s[1]; x += alpha p; r -= alpha Ap; s[2] = <r, minv r>; s[3] = <r,r>
- *                          update_p:  beta = s[2]/s[0]; p = minv r + beta p; then s[0] <- s[2]
- *                        (init and update_xr write LOCAL sums into s[2], s[3]; all-reduce them before the next call;
- *                        after init also copy s[2] to s[0] once the reduced value is in place) */
+ *                        Rows with minv == 0 (a preconditioner zeroed on constrained dofs; damping 0) are frozen: x keeps
+ *                        its initial value there and the row is left out of the residual norm (the iteration keeps
+ *                        z = M^-1 r, from which r cannot be recovered where minv = 0)
+ *   l3k_cg_*           : the fused vector kernels of one iteration for partitioned vectors; the caller all-reduces the
+ *                        device scalar block s[8] (0 <r,z>, 1 <p,Ap>, 2 <r,z> new, 3 <r,r>) between them.  Protocol below
+ *                        (l3k_cg_init, _dot_pap, _update_z, _update_px): init and update_z write LOCAL sums into s[2], s[3];
+ *                        all-reduce them before the next call; after init also copy s[2] to s[0] once the reduced value is
+ *                        in place. */
 typedef struct
 {
     double tol;

@@ -11,6 +11,7 @@
 #define L3K_KERNEL_INTERFACE_HPP
 
 #include <cstddef>
+#include <utility>
 
 #if defined(__HIPCC__)
 #define L3K_HD __host__ __device__ __attribute__((always_inline)) inline
@@ -48,6 +49,9 @@ struct Matrix
     static constexpr int cols() { return Cols; }
 };
 
+// field values / one derivative direction of the F external fields.  Like the reference's std::array it decomposes with
+// structured bindings (benchmarks/Kernels.hpp:5-9: `const auto& [u, v, w, p, ox, oy, oz] = vals;`) and iterates
+// (examples/04-periodic-bc/source.cpp:74: std::transform_reduce over field_vals)
 template < int F >
 struct FieldArray
 {
@@ -55,6 +59,20 @@ struct FieldArray
     L3K_HD double&       operator[](int i) { return v[i]; }
     L3K_HD const double& operator[](int i) const { return v[i]; }
     static constexpr int size() { return F; }
+    L3K_HD const double* begin() const { return v; }
+    L3K_HD const double* end() const { return v + F; }
+    template < std::size_t I >
+    L3K_HD const double& get() const
+    {
+        static_assert(I < std::size_t(F > 0 ? F : 1));
+        return v[I];
+    }
+    template < std::size_t I >
+    L3K_HD double& get()
+    {
+        static_assert(I < std::size_t(F > 0 ? F : 1));
+        return v[I];
+    }
 };
 
 // common/Structs.hpp: Point<3>, SpaceTimePoint
@@ -189,4 +207,14 @@ constexpr auto wrapBoundaryResidualKernel(Kernel kernel)
     return ResidualBoundaryKernel< Kernel, params >{kernel};
 }
 } // namespace l3k
+
+// tuple-like protocol of FieldArray (structured bindings)
+template < int F >
+struct std::tuple_size< l3k::FieldArray< F > > : std::integral_constant< std::size_t, std::size_t(F) >
+{};
+template < std::size_t I, int F >
+struct std::tuple_element< I, l3k::FieldArray< F > >
+{
+    using type = double;
+};
 #endif

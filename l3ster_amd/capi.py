@@ -78,6 +78,13 @@ class MeshFilePartDesc(C.Structure):
                 ("boundary_ids", c_uint16_p)]
 
 
+class Tuning(C.Structure):
+    """l3k_tuning: the launch-route settings of a context (include/l3k.h)"""
+    _fields_ = [("generic_below", C.c_int64), ("static_deal", C.c_int), ("waves_per_cu", C.c_int), ("no_affine", C.c_int),
+                ("column_by_column", C.c_int), ("assemble_dense", C.c_int), ("assemble_two_launches", C.c_int),
+                ("scatter_per_entry", C.c_int)]
+
+
 # every symbol include/l3k.h declares: (name, restype, argtypes)
 _vp = C.c_void_p
 SIGNATURES = {
@@ -95,6 +102,10 @@ SIGNATURES = {
     "l3k_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "l3k_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "l3k_ctx_set_deterministic": (C.c_int, [_vp, C.c_int]),
+    "l3k_ctx_set_reference_z0": (C.c_int, [_vp, C.c_int]),
+    "l3k_ctx_get_tuning": (C.c_int, [_vp, C.POINTER(Tuning)]),
+    "l3k_ctx_set_tuning": (C.c_int, [_vp, C.POINTER(Tuning)]),
+    "l3k_mf_route": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "l3k_ctx_synchronize": (C.c_int, [_vp]),
     "l3k_ctx_destroy": (C.c_int, [_vp]),
     "l3k_mesh_create": (C.c_int, [_vp, C.POINTER(MeshDesc), C.POINTER(_vp)]),

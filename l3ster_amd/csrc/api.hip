@@ -189,9 +189,9 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.exclusive_node_end   = m->exclusive_end;
     a.slot_tab             = m->slot_tab.ptr;
     a.all_affine           = m->all_affine ? 1 : 0;
-    // dynamic batch distribution of the single-wave kernel (L3K_FAST_STATIC=1: the static deal)
-    const bool static_deal = std::getenv("L3K_FAST_STATIC") != nullptr; // (read per launch: the tests switch it)
-    a.work_counters        = static_deal ? nullptr : mf->ctx->work_counters;
+    a.tune                 = &mf->ctx->tune;
+    // dynamic batch distribution of the single-wave kernel (l3k_tuning::static_deal: the static deal)
+    a.work_counters        = mf->ctx->tune.static_deal ? nullptr : mf->ctx->work_counters;
     a.energy        = ncols == 1 ? mf->energy_target : nullptr;
     a.energy_done   = &mf->energy_done;
     a.n_shell              = m->n_shell;
@@ -202,17 +202,19 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.n_owned_dofs    = m->nOwnedDofs();
     a.time            = mf->time;
     a.dofs_per_node   = m->dofs_per_node;
+#ifdef L3K_ABLATION // (tools/kbench.py's switches exist in the ablation build only)
     static const int dbg_flags = [] {
         const char* e = std::getenv("L3K_DEBUG_FLAGS");
         return e ? std::atoi(e) : 0;
     }();
-    a.dbg   = dbg_flags;
-#ifdef L3K_ABLATION
+    a.dbg    = dbg_flags;
     a.stamps = debugStamps();
 #else
+    a.dbg    = 0;
     a.stamps = nullptr;
 #endif
-    a.dense = mf->dense;
+    a.dense  = mf->dense;
+    a.ref_z0 = mf->ctx->reference_z0 ? 1 : 0;
     for (int u = 0; u < l3k::dev::max_unknowns; ++u)
         a.field_inds[u] = mf->field_inds[u];
     switch (which)
@@ -648,8 +650,23 @@ int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
     }
     L3K_HIP(hipSetDevice(hip_device));
     auto* ctx = new l3k_ctx{hip_device, static_cast< hipStream_t >(hip_stream)};
+    // the ONLY place the product reads the environment: initial values of the context's settings (include/l3k.h: l3k_tuning)
     if (const char* e = std::getenv("L3K_DETERMINISTIC"))
         ctx->deterministic = std::atoi(e) != 0;
+    const auto flag = [](const char* name, int& field) {
+        if (const char* e = std::getenv(name))
+            field = *e != '\0' && std::strcmp(e, "0") != 0;
+    };
+    if (const char* e = std::getenv("L3K_GENERIC_BELOW"))
+        ctx->tune.generic_below = std::atoll(e);
+    if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
+        ctx->tune.waves_per_cu = std::atoi(e) > 0 ? std::atoi(e) : 0;
+    flag("L3K_FAST_STATIC", ctx->tune.static_deal);
+    flag("L3K_NO_AFFINE", ctx->tune.no_affine);
+    flag("L3K_COLUMN_BY_COLUMN", ctx->tune.column_by_column);
+    flag("L3K_ASSEMBLE_DENSE", ctx->tune.assemble_dense);
+    flag("L3K_ASM_TWO_LAUNCHES", ctx->tune.assemble_two_launches);
+    flag("L3K_SCATTER_PER_ENTRY", ctx->tune.scatter_per_entry);
     // the context's own device buffers are allocated here, with its device current: a later call may come from a thread
     // whose current device is another one (several contexts in one process: thread-emulated ranks, a multi-GPU C++ host)
     if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 9 * 128) != hipSuccess ||
@@ -680,6 +697,41 @@ int l3k_ctx_set_deterministic(l3k_ctx* ctx, int on)
         return -1;
     }
     ctx->deterministic = on != 0;
+    return 0;
+}
+int l3k_ctx_set_reference_z0(l3k_ctx* ctx, int on)
+{
+    if (!ctx)
+    {
+        setError("null context");
+        return -1;
+    }
+    ctx->reference_z0 = on != 0;
+    return 0;
+}
+int l3k_ctx_get_tuning(const l3k_ctx* ctx, l3k_tuning* out)
+{
+    if (!ctx || !out)
+    {
+        setError("l3k_ctx_get_tuning: null argument");
+        return -1;
+    }
+    *out = ctx->tune;
+    return 0;
+}
+int l3k_ctx_set_tuning(l3k_ctx* ctx, const l3k_tuning* in)
+{
+    if (!ctx || !in)
+    {
+        setError("l3k_ctx_set_tuning: null argument");
+        return -1;
+    }
+    if (in->generic_below < 0 || in->waves_per_cu < 0 || in->waves_per_cu > 64)
+    {
+        setError("l3k_ctx_set_tuning: generic_below must be >= 0 and waves_per_cu in [0, 64]");
+        return -1;
+    }
+    ctx->tune = *in;
     return 0;
 }
 int l3k_ctx_synchronize(l3k_ctx* ctx)
@@ -976,6 +1028,57 @@ int l3k_mf_set_time(l3k_mf* mf, double time)
     return 0;
 }
 
+int l3k_mf_route(l3k_mf* mf, int which, int ncols, int with_energy, char* buf, size_t n)
+{
+    if (!mf || !buf || n == 0)
+    {
+        setError("l3k_mf_route: null argument");
+        return -1;
+    }
+    buf[0] = '\0';
+    l3k::dev::ElemArgs a;
+    double* const      saved = mf->energy_target;
+    if (with_energy)
+        mf->energy_target = reinterpret_cast< double* >(mf->ctx->red_ws); // (any non-null device pointer: nothing is launched)
+    const int rc      = fillArgs(mf, which, ncols, a);
+    mf->energy_target = saved;
+    if (rc)
+        return rc;
+    if (mf->ctx->deterministic)
+        a.energy = nullptr; // (forEachLaunchRange)
+    const l3k_mesh* m = mf->mesh;
+    // the pointer relations the launcher looks at: ghost rows in buffers of their own whenever the mesh has ghost nodes and the
+    // launch covers border elements (l3k_mf_apply_elems is given separate import / export buffers)
+    static const double dummy[2] = {0., 0.};
+    a.x = a.y = nullptr;
+    a.xg = a.yg = (m->n_ghost_nodes > 0 && (which == 1 || which == 2)) ? const_cast< double* >(dummy) : nullptr;
+    a.fuse_beta = mf->fuse;
+    const auto* inst = l3k::dev::findInstance(mf->kernel_id, m->order, mf->nq, ncols);
+    bool        looped = false;
+    if (!inst)
+    {
+        inst = instanceFor(mf, 1);
+        if (!inst)
+            return -4;
+        if (inst->apply_cols && mf->dense && !mf->ctx->deterministic && !mf->ctx->tune.column_by_column)
+            a.n_cols = ncols;
+        else
+            looped = ncols > 1;
+    }
+    if (!inst->route)
+    {
+        setError("this instance carries no route description");
+        return -4;
+    }
+    if (int rc2 = inst->route(a, buf, n))
+        return rc2;
+    const size_t len = std::strlen(buf);
+    if (const auto* meta = l3k::api::findKernel(mf->kernel_id))
+        std::snprintf(buf + len, n - len, " [kernel %d \"%s\"%s%s%s]", mf->kernel_id, meta->name, looped ? ", column by column" : "",
+                      mf->ctx->deterministic ? ", deterministic: one launch per colour" : "", mf->ctx->reference_z0 ? ", reference z=0" : "");
+    return 0;
+}
+
 int l3k_mf_scale(l3k_mf* mf, double* d_y, size_t ldy, int ncols, double beta)
 {
     if (!mf || !d_y)
@@ -1066,7 +1169,7 @@ int l3k_mf_apply_elems(l3k_mf* mf, int which, const double* d_x, size_t ldx, con
         inst = instanceFor(mf, 1);
         if (!inst)
             return -4;
-        if (inst->apply_cols && mf->dense && !mf->ctx->deterministic && std::getenv("L3K_COLUMN_BY_COLUMN") == nullptr) // (the switch: cross-check)
+        if (inst->apply_cols && mf->dense && !mf->ctx->deterministic && !mf->ctx->tune.column_by_column) // (the switch: cross-check)
         {
             // dense dof layout: all columns in one pass over the elements (node ids, flags and the work ticket once per
             // element), MatrixFreeSystem.hpp:678-688
@@ -1452,11 +1555,8 @@ int l3k_assemble_global(l3k_mf* mf, int64_t first, int64_t count, const int64_t*
         return -4;
     L3K_HIP(hipSetDevice(mf->ctx->device));
     // element matrices between the two kernels in the tiled layout where the sum-factorised assembly kernel exists (its stores
-    // coalesce, the scatter transposes a row through LDS); L3K_GLOBAL_ROW_MAJOR=1 keeps the reference's row-major layout
-    const int    tiled = inst->assemble_tiled && mf->kp.n_unknowns <= 4 && m->order <= 7 && std::getenv("L3K_GLOBAL_ROW_MAJOR") == nullptr &&
-                               std::getenv("L3K_ASSEMBLE_DENSE") == nullptr
-                           ? 1
-                           : 0;
+    // coalesce, the scatter transposes a row through LDS); the dense cross-check kernel writes the reference's row-major layout
+    const int    tiled = inst->assemble_tiled && mf->kp.n_unknowns <= 4 && m->order <= 7 && !mf->ctx->tune.assemble_dense ? 1 : 0;
     const int    N1 = m->order + 1, Nd = N1 * N1 * N1 * mf->kp.n_unknowns, R = mf->n_rhs;
     const size_t per_elem = sizeof(double) * (size_t(Nd) * Nd + size_t(Nd) * R + inst->assemble_ws_doubles);
     if (workspace_bytes == 0)

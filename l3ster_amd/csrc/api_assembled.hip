@@ -27,7 +27,7 @@ struct ScatterArgs
     int             field_inds[l3k::dev::max_unknowns];
 };
 
-// The round-2 form, kept behind L3K_SCATTER_PER_ENTRY=1 as the cross-check (tests) and the baseline (tools/bench_assembled_pipeline.py):
+// The round-2 form, kept behind l3k_tuning::scatter_per_entry as the cross-check (tests) and the baseline (tools/bench_assembled_pipeline.py):
 // one wave per (element, local row), a binary search per ENTRY
 __global__ __launch_bounds__(64) void assembledScatterPerEntryKernel(const ScatterArgs a)
 {
@@ -39,8 +39,9 @@ __global__ __launch_bounds__(64) void assembledScatterPerEntryKernel(const Scatt
     if (a.skip_dirichlet && a.dirichlet && a.dirichlet[row])
         return;
     const int lane = threadIdx.x;
-    if (a.F && a.rhs && lane < a.n_rhs)
-        unsafeAtomicAdd(a.rhs + size_t(lane) * a.ldr + row, a.F[(e * a.n_rhs + lane) * Nd + i]);
+    if (a.F && a.rhs)
+        for (int r = lane; r < a.n_rhs; r += 64) // (more than 64 right-hand sides: several rounds)
+            unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row, a.F[(e * a.n_rhs + r) * Nd + i]);
     if (!a.K || !a.values)
         return;
     const int64_t  rb = a.row_ptr[row], re = a.row_ptr[row + 1];
@@ -107,12 +108,22 @@ __global__ __launch_bounds__(64) void assembledScatterKernel(const ScatterArgs a
         row[u]  = nb + a.field_inds[u];
         live[u] = !(a.skip_dirichlet && a.dirichlet && a.dirichlet[row[u]]);
     }
-    if (a.F && a.rhs && lane < a.n_rhs * U)
-    {
-        const int r = lane / U, u = lane - r * U;
-        if (live[u])
-            unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row[u], a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
-    }
+    if (a.F && a.rhs)
+        for (int t = lane; t < a.n_rhs * U; t += 64) // (n_rhs * U may exceed the wave: e.g. 17 right-hand sides of 4 unknowns)
+        {
+            const int r = t / U, u = t - r * U;
+            bool      lv = false;
+            int64_t   rw = 0;
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) // (compile-time indexing of the per-unknown registers)
+                if (uu == u)
+                {
+                    lv = live[uu];
+                    rw = row[uu];
+                }
+            if (lv)
+                unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + rw, a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
+        }
     if (!a.K || !a.values)
         return;
 #pragma unroll
@@ -166,13 +177,14 @@ __global__ __launch_bounds__(64) void assembledScatterTiledKernel(const ScatterA
     const int       lane = threadIdx.x;
     const int64_t   nb   = int64_t(en[b]) * a.dpn;
     const int       bx = b % N1, by = (b / N1) % N1, bz = b / N2; // row node b = bx + N1 (by + N1 bz)
-    if (a.F && a.rhs && lane < a.n_rhs * U)
-    {
-        const int     r = lane / U, u = lane - r * U;
-        const int64_t row = nb + a.field_inds[u];
-        if (!(a.skip_dirichlet && a.dirichlet && a.dirichlet[row]))
-            unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row, a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
-    }
+    if (a.F && a.rhs)
+        for (int t = lane; t < a.n_rhs * U; t += 64) // (n_rhs * U may exceed the wave)
+        {
+            const int     r = t / U, u = t - r * U;
+            const int64_t row = nb + a.field_inds[u];
+            if (!(a.skip_dirichlet && a.dirichlet && a.dirichlet[row]))
+                unsafeAtomicAdd(a.rhs + size_t(r) * a.ldr + row, a.F[(e * a.n_rhs + r) * Nd + b * U + u]);
+        }
     if (!a.K || !a.values)
         return;
     const double* Ke       = a.K + e * int64_t(Nd) * Nd;
@@ -294,7 +306,7 @@ int launchAssembledScatter(l3k_mf* mf, int64_t first, int64_t count, const doubl
             return -1;
         }
     }
-    else if (std::getenv("L3K_SCATTER_PER_ENTRY"))
+    else if (mf->ctx->tune.scatter_per_entry) // (the round-2 kernel, kept as the cross-check of the per-row-node one)
     {
         const int64_t rows = count * NN * mf->kp.n_unknowns;
         if (rows > int64_t(0x7fffffff))

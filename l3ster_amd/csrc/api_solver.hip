@@ -54,7 +54,9 @@ __global__ __launch_bounds__(cg_threads) void cgFinishKernel(const double* __res
 //   p pass:  x += alpha p; beta = s[2]/s[0]; p = z + beta p                                       reads z, p, x;   writes p, x
 // (round 2: x += alpha p and r -= alpha Ap in one pass over x, r, p, Ap, minv, then p = minv r + beta p over r, minv, p.)
 // The same iterates in exact arithmetic; in floating point z is updated where r was (one rounding of minv * Ap more, one of
-// minv * r less).
+// minv * r less).  Rows with minv == 0 (a preconditioner zeroed on constrained dofs, l3k_jacobi_inverse with damping 0) are FROZEN:
+// z = p = 0 there, x keeps its initial value, and -- since r cannot be recovered from z = 0 -- they are left out of <r, r>, i.e.
+// the convergence test runs over the rows the iteration can change (include/l3k.h: l3k_pcg_solve).
 __global__ __launch_bounds__(cg_threads) void cgUpdateZKernel(double* __restrict__ z, const double* __restrict__ ap,
                                                               const double* __restrict__ minv, int64_t n,
                                                               const double* __restrict__ s, double* __restrict__ partial)
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(cg_threads) void cgUpdateZKernel(double* __restrict
     {
         const double m  = minv ? minv[i] : 1.;
         const double zi = z[i] - alpha * (m * ap[i]);
-        const double ri = minv ? zi / m : zi;
+        const double ri = minv ? (m != 0. ? zi / m : 0.) : zi; // (0 / 0 on a frozen row would poison both sums)
         z[i]            = zi;
         rz += ri * zi;
         rr += ri * ri;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(cg_threads) void cgInitKernel(double* __restrict__ 
     double            rz = 0., rr = 0.;
     for (int64_t i = int64_t(blockIdx.x) * cg_threads + threadIdx.x; i < n; i += int64_t(gridDim.x) * cg_threads)
     {
-        const double ri = b[i] - r[i];
-        const double zi = minv ? minv[i] * ri : ri;
+        const double m  = minv ? minv[i] : 1.;
+        const double ri = m != 0. ? b[i] - r[i] : 0.; // (frozen rows: out of the residual norm from the start, as in the z pass)
+        const double zi = m * ri;
         r[i]            = zi;
         p[i]            = zi;
         rz += ri * zi;

@@ -546,7 +546,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
     // 64-byte line of K_e receives its 8 entries from 4 pair-workgroups (the unknown u' is the fastest index of a row), so
     // they should at least meet in one L2.  Otherwise blockIdx = pair + NP * element.
     static_assert(!TILED || BLOCKS == 0);
-    constexpr int NP = TILED ? U * U : (BLOCKS == 1 ? U : (BLOCKS == 2 ? U * (U - 1) / 2 : U * (U + 1) / 2));
+    // (a single unknown has no off-diagonal block: that kernel is instantiated but never launched)
+    constexpr int NP = TILED ? U * U : (BLOCKS == 1 ? U : (BLOCKS == 2 ? cmax(U * (U - 1) / 2, 1) : U * (U + 1) / 2));
     int64_t       el;
     int           rem;
     if (xcd_group)
@@ -1243,8 +1244,9 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     }
     double* cbuf = a.workspace; // coeffStride * nq^3 doubles per element, + 1 flag
     hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
-    // the sum-factorised kernel unless it does not fit or L3K_ASSEMBLE_DENSE=1 asks for the dense MFMA product (cross-check)
-    const bool dense = !S::feasible || (std::getenv("L3K_ASSEMBLE_DENSE") != nullptr && !a.K_tiled);
+    // the sum-factorised kernel unless it does not fit or l3k_tuning::assemble_dense asks for the dense MFMA product (cross-check)
+    const l3k_tuning& tune  = tuneOf(a);
+    const bool        dense = !S::feasible || (tune.assemble_dense && !a.K_tiled);
     if (a.K_tiled && (!S::feasible || !a.K))
     {
         setError("the tiled layout of the element matrices needs the sum-factorised assembly kernel (this shape has none)");
@@ -1255,7 +1257,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         {
             // (stored modes: the partial 64-byte lines of K_e meet in one L2; streaming mode: the element's coefficient records are
             // fetched into one L2 instead of up to eight: +2.3 %, 516 -> 528 k matrices/s at order 6)
-            const int xcd_group = std::getenv("L3K_ASM_NO_XCD") == nullptr;
+            constexpr int xcd_group = 1;
             auto      launch    = [&](auto ks, int NP, int threads, size_t lds_bytes) {
                 const int64_t n_blocks = xcd_group ? ((a.elem_count + 7) / 8) * 8 * NP : a.elem_count * NP;
                 if (n_blocks > int64_t(0x7fffffff))
@@ -1270,7 +1272,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
             };
             // the diagonal and the off-diagonal blocks as two launches (a register allocation each); one launch over all pairs
             // where the workgroups of an element should meet in one L2 (stored row-major matrices) or on request
-            const bool one_launch = std::getenv("L3K_ASM_ONE_LAUNCH") != nullptr || (a.K != nullptr && std::getenv("L3K_ASM_TWO_LAUNCHES") == nullptr);
+            const bool one_launch = a.K != nullptr && !tune.assemble_two_launches;
             int        rc         = 0;
             if (a.K_tiled)
                 rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U, S::threadsFor(true, 0), S::ldsFor(true, 0));

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "l3k.h"
 #include "l3k/kernel_interface.hpp"
 
 // Ablation switches (tools/kbench.py) exist only in a library built with L3K_ABLATION=1 (python -m l3ster_amd.build
@@ -93,6 +94,8 @@ struct ElemArgs
     int     local_out;      // RHS-mode kernel writes element-local F_e instead of scattering
     int     all_affine; // every element of the mesh is a parallelepiped (one Jacobian per element)
     int     n_cols;     // single-wave kernel, multi-column variant: columns applied per element pass (0 / 1: one)
+    const l3k_tuning* tune; // HOST: the context's launch-route settings (read by the launchers; nullptr: defaults)
+    int     ref_z0;     // applies pass z = 0 to the domain kernel (the reference's evalAtHexQPs, SumFactorization.hpp:732) instead of the true z
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
     long long* stamps; // L3K_ABLATION builds with env L3K_STAMPS: per-stage cycle counters of workgroup 0 ([iteration][16])
@@ -107,6 +110,14 @@ struct ElemArgs
 };
 
 using LaunchFn = int (*)(const ElemArgs&, const void* kparam_blob, hipStream_t stream);
+using RouteFn  = int (*)(const ElemArgs&, char* buf, size_t n); // describes the kernel a launch with these arguments takes
+
+// the launch-route settings of a launch: the context's, or the defaults (host/registry.cpp)
+const l3k_tuning& defaultTuning();
+inline const l3k_tuning& tuneOf(const ElemArgs& a)
+{
+    return a.tune ? *a.tune : defaultTuning();
+}
 
 struct Instance
 {
@@ -117,6 +128,7 @@ struct Instance
     size_t   assemble_ws_doubles; // workspace doubles per element for `assemble`
     LaunchFn apply_cols = nullptr; // ncols == 1 instances: applies a.n_cols columns in one pass over the elements, or nullptr
     bool     assemble_tiled = false; // `assemble` can write the tiled layout (ElemArgs::K_tiled): the sum-factorised kernel fits
+    RouteFn  route = nullptr; // text description of the kernel `apply` (or `apply_cols`, with a.n_cols > 1) launches
 };
 
 // boundary equation kernel on element sides (device/boundary.hpp)

@@ -3,6 +3,7 @@
 #ifndef L3K_DEVICE_INSTANTIATE_HPP
 #define L3K_DEVICE_INSTANTIATE_HPP
 
+#include <cstring>
 #include <type_traits>
 
 #include "../user_kernels.hpp"
@@ -83,6 +84,26 @@ constexpr LaunchFn selectApply()
     else
         return &launchSumfactApply< T, P, NQ, R, false >;
 }
+// the route text of an instance's apply (l3k_mf_route)
+template < typename T, int P, int NQ, int R >
+constexpr RouteFn selectRoute()
+{
+    if constexpr (FastCfg< T, P, NQ >::feasible && R == 1)
+        return &describeSumfactFast< T, P, NQ >;
+    else if constexpr (FastCfg< T, P, NQ >::feasible)
+        return +[](const ElemArgs& a, char* buf, size_t n) {
+            if (!a.dense)
+                return describeSumfactApply< T, P, NQ, R >(a, buf, n);
+            ElemArgs ac = a; // launchColumnsFast: one multi-column pass, or R launches of the single-column kernel
+            ac.n_cols   = R;
+            const int rc = describeSumfactFast< T, P, NQ >(ac, buf, n);
+            if (rc == 0 && !FastCfg< T, P, NQ >::multi_column)
+                std::snprintf(buf + std::strlen(buf), n - std::strlen(buf), "; %d launches, one per column", R);
+            return rc;
+        };
+    else
+        return &describeSumfactApply< T, P, NQ, R >;
+}
 } // namespace l3k::dev
 
 #define L3K_CAT2(a, b) a##b
@@ -100,7 +121,8 @@ constexpr LaunchFn selectApply()
                                           &::l3k::dev::launchAssemble< T, P, NQ >,                                 \
                                           ::l3k::dev::assembleWorkspaceDoublesPerElem< T, P, NQ >(),               \
                                           ::l3k::dev::selectApplyCols< T, P, NQ, R >(),                              \
-                                          ::l3k::dev::SfAsmCfg< P, NQ >::feasible});                                 \
+                                          ::l3k::dev::SfAsmCfg< P, NQ >::feasible,                                   \
+                                          ::l3k::dev::selectRoute< T, P, NQ, R >()});                                \
         }                                                                                                              \
     } L3K_CAT(registrar_, __LINE__);                                                                                   \
     }

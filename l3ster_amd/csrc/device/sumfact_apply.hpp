@@ -16,6 +16,7 @@
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdio>
 #include <utility>
 
 namespace l3k::dev
@@ -146,7 +147,7 @@ __device__ __forceinline__ double inverse3(const double M[3][3], double Mi[3][3]
 template < typename K, int R, bool RHS_MODE, int RT, int C0, bool ENERGY >
 __device__ __forceinline__ void qpStageAt(const K& kern, const double (*Ji)[3], double det, const double* xyz, double w_ref, double time,
                                           const double* v, const double (*dv)[K::params.n_unknowns * R + K::params.n_fields], double* r0,
-                                          double (*rd)[K::params.n_unknowns * R], double* energy);
+                                          double (*rd)[K::params.n_unknowns * R], double* energy, bool ref_z0);
 // ENERGY: *energy += sum_e wgt * (B x)_e^2, this point's share of x^T A x.
 template < typename K, int R, bool RHS_MODE, int RT = R, int C0 = 0, bool ENERGY = false >
 __device__ __forceinline__ void qpStage(const K&      kern,
@@ -158,12 +159,13 @@ __device__ __forceinline__ void qpStage(const K&      kern,
                                         const double (*dv)[K::params.n_unknowns * R + K::params.n_fields],
                                         double*       r0,
                                         double (*rd)[K::params.n_unknowns * R],
-                                        double*       energy = nullptr)
+                                        double*       energy = nullptr,
+                                        bool          ref_z0 = false)
 {
     double Jm[3][3], Ji[3][3], xyz[3];
     hexPointOnPencil(G, xi, Jm, xyz);
     const double det = inverse3(Jm, Ji);
-    qpStageAt< K, R, RHS_MODE, RT, C0, ENERGY >(kern, Ji, det, xyz, w_ref, time, v, dv, r0, rd, energy);
+    qpStageAt< K, R, RHS_MODE, RT, C0, ENERGY >(kern, Ji, det, xyz, w_ref, time, v, dv, r0, rd, energy, ref_z0);
 }
 // the same with the geometry of the point given: Ji = (dx/dxi)^{-1} (Ji[d][s] = d xi_d / d x_s), det, position
 template < typename K, int R, bool RHS_MODE, int RT, int C0, bool ENERGY >
@@ -177,7 +179,8 @@ __device__ __forceinline__ void qpStageAt(const K&      kern,
                                           const double (*dv)[K::params.n_unknowns * R + K::params.n_fields],
                                           double*       r0,
                                           double (*rd)[K::params.n_unknowns * R],
-                                          double*       energy)
+                                          double*       energy,
+                                          bool          ref_z0)
 {
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations, F = params.n_fields, OPS = U * R;
@@ -193,7 +196,11 @@ __device__ __forceinline__ void qpStageAt(const K&      kern,
         for (int s = 0; s < 3; ++s) // algsys/SumFactorization.hpp:596-612
             in.field_ders[s][f] = Ji[0][s] * dv[0][OPS + f] + Ji[1][s] * dv[1][OPS + f] + Ji[2][s] * dv[2][OPS + f];
     }
-    in.point = SpaceTimePoint{Point3{{xyz[0], xyz[1], xyz[2]}}, time}; // true z (reference passes 0: SURVEY.md D8)
+    // The true point by default.  ref_z0 (l3k_ctx_set_reference_z0): the apply hands the kernel Point{x, y, 0.} as the
+    // reference's evalAtHexQPs does (algsys/SumFactorization.hpp:732); diag / rhs follow the reference's
+    // local-element path, which passes the true point (algsys/AssembleLocalSystem.hpp:229-230).  A kernel that does not read
+    // point.space.z() compiles to the same code either way
+    in.point = SpaceTimePoint{Point3{{xyz[0], xyz[1], (!RHS_MODE && ref_z0) ? 0. : xyz[2]}}, time};
     typename Iface::Result res{};
     kern(in, res);
 
@@ -351,7 +358,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
         const double* qp = a.tables + TL.offX();
         double G[6][3];
         hexPencilGeom(vs, qp[qy], qp[qz], G);
-        qpStage< K, R, RHS_MODE, RT, C0 >(kern, G, qp[qx], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd);
+        qpStage< K, R, RHS_MODE, RT, C0 >(kern, G, qp[qx], qw[qx] * qw[qy] * qw[qz], a.time, v, dv, r0, rd, nullptr, a.ref_z0 != 0);
 #pragma unroll
         for (int o = 0; o < OPS; ++o)
         {
@@ -420,6 +427,18 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
 }
 
 inline constexpr size_t lds_limit_bytes = 160 * 1024; // LDS per CU on gfx950; one workgroup may use all of it
+
+// the route of a launch through the generic kernel as text (l3k_mf_route)
+template < typename K, int P, int NQ, int R >
+int describeSumfactApply(const ElemArgs& a, char* buf, size_t n)
+{
+    constexpr bool by_columns = applyLdsBytes< K, P, NQ, R >() > lds_limit_bytes && R > 1;
+    std::snprintf(buf, n, "sumfactApplyKernel<p=%d,nq=%d,U=%d,F=%d,R=%d>: generic LDS kernel, one element per %d-thread workgroup, %zu B LDS%s%s",
+                  P, NQ, K::params.n_unknowns, K::params.n_fields, by_columns ? 1 : R, applyThreads< P, NQ >(),
+                  applyLdsBytes< K, P, NQ, by_columns ? 1 : R >(), by_columns ? ", column by column (the R-column working set exceeds the LDS)" : "",
+                  a.dense ? "" : ", non-dense dof layout");
+    return 0;
+}
 
 template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
 int launchSumfactApply(const ElemArgs& a, const void* kparam_blob, hipStream_t stream);

@@ -24,6 +24,7 @@
 
 #include "sumfact_apply.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -744,10 +745,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 if constexpr (AFFINE)
                 {
                     const double xyz[3] = {G[0][0] + qp[q] * G[1][0], G[0][1] + qp[q] * G[1][1], G[0][2] + qp[q] * G[1][2]};
-                    qpStageAt< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                    qpStageAt< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
                 }
                 else
-                    qpStage< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en);
+                    qpStage< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -1187,61 +1188,41 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
 #endif
 }
 
+// What a launch of the single-wave kernel will do: decided in ONE place (planSumfactFast), used by the launcher and by the route
+// report of l3k_mf_route.  The settings come from the context's l3k_tuning (read from the environment once, at l3k_ctx_create).
+struct FastRoute
+{
+    bool     generic = false; // the launch goes to the generic LDS kernel instead (small launch, or a non-dense dof layout)
+    bool     split = false, affine = false, energy = false, multi = false, dynamic = false;
+    int      waves_cu = 0, xcd_chunk = 0, n_cus = 0;
+    unsigned grid = 0;
+    int64_t  n_batches = 0;
+};
 template < typename K, int P, int NQ, bool MULTI >
-int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+int planSumfactFast(const ElemArgs& a, FastRoute& r)
 {
     using Cfg = FastCfg< K, P, NQ >;
-    if (a.elem_count <= 0)
-        return 0;
-    if (MULTI && a.n_cols < 1)
-    {
-        setError("multi-column element launch without a column count");
-        return -1;
-    }
+    const l3k_tuning& tune = tuneOf(a);
+    r       = FastRoute{};
+    r.multi = MULTI;
     // Small launches are latency-bound: one element takes ~23 us through a single wave here, ~15 us through the 6-wave
     // workgroup of the generic kernel; below ~3 elements per CU the generic kernel wins (profiles/r01_kbench_small_meshes.log:
-    // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements).  L3K_GENERIC_BELOW overrides.
-    const char* const gb_env        = std::getenv("L3K_GENERIC_BELOW"); // (read per launch: the tests switch it)
-    const long        generic_below = gb_env ? std::atol(gb_env) : 1500L;
+    // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements): l3k_tuning::generic_below
     constexpr bool generic_fits = applyLdsBytes< K, P, NQ, 1 >() <= lds_limit_bytes;
-    if (!a.dense || (generic_fits && a.elem_count < generic_below)) // (non-dense dof layouts: generic kernel only)
+    if (!a.dense || (generic_fits && a.elem_count < tune.generic_below)) // (non-dense dof layouts: generic kernel only)
     {
-        if constexpr (!MULTI)
-            return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);
-        else
-        {
-            for (int c = 0; c < a.n_cols; ++c) // column by column through the generic single-column kernel
-            {
-                ElemArgs ac = a;
-                ac.n_cols   = 1;
-                ac.x        = a.x + a.ldx * c;
-                ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
-                ac.y        = a.y + a.ldy * c;
-                ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
-                if (int rc = launchSumfactApply< K, P, NQ, 1, false >(ac, kparam_blob, stream))
-                    return rc;
-            }
-            return 0;
-        }
+        r.generic = true;
+        return 0;
     }
-    K kern{};
-    if (kparam_blob)
-        __builtin_memcpy(&kern, kparam_blob, sizeof(K));
     // (ghost rows directly behind the owned rows of every column: one base pointer per column serves both)
-    const bool  contiguous = (a.xg == nullptr || (a.xg == a.x + a.n_owned_dofs && (!MULTI || a.ldxg == a.ldx))) &&
+    const bool contiguous = (a.xg == nullptr || (a.xg == a.x + a.n_owned_dofs && (!MULTI || a.ldxg == a.ldx))) &&
                             (a.yg == nullptr || (a.yg == a.y + a.n_owned_dofs && (!MULTI || a.ldyg == a.ldy)));
-    const bool  split    = !contiguous;
+    r.split  = !contiguous;
     // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
-    const bool  affine   = !MULTI && a.all_affine && !split && !a.energy && std::getenv("L3K_NO_AFFINE") == nullptr;
-    decltype(&sumfactFastKernel< K, P, NQ, false, false >) kernel;
-    if constexpr (MULTI) // (no fused energy, no affine variant: plain applies of several columns)
-        kernel = split ? sumfactFastKernel< K, P, NQ, true, false, false, true > : sumfactFastKernel< K, P, NQ, false, false, false, true >;
-    else
-        kernel = affine ? sumfactFastKernel< K, P, NQ, false, false, true >
-                 : a.energy ? (split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
-                            : (split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
+    r.affine = !MULTI && a.all_affine && !r.split && !a.energy && !tune.no_affine;
+    r.energy = !MULTI && a.energy != nullptr;
     // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
-    // attribute of the four variants is set once on each device, under a lock
+    // attribute of the variants is set once on each device, under a lock
     struct PerDevice
     {
         bool ready = false;
@@ -1256,7 +1237,6 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
         setError("device index %d not supported", dev);
         return -3;
     }
-    int n_cus, waves_cu;
     {
         std::lock_guard< std::mutex > lock{per_device_mutex};
         PerDevice&                    pd = per_device[dev];
@@ -1287,18 +1267,70 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
                 return -3;
             }
             pd.n_cus = prop.multiProcessorCount;
-            // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the 256-VGPR budget (2 per SIMD)
+            // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the VGPR budget (min_waves per SIMD)
             const int by_lds = int((160 * 1024) / Cfg::lds);
             pd.waves_cu      = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::min_waves ? 4 * Cfg::min_waves : by_lds);
             pd.ready         = true;
         }
-        n_cus = pd.n_cus, waves_cu = pd.waves_cu;
+        r.n_cus = pd.n_cus, r.waves_cu = pd.waves_cu;
     }
-    if (const char* e = std::getenv("L3K_FAST_WAVES_PER_CU"))
-        waves_cu = std::atoi(e) > 0 ? std::atoi(e) : waves_cu;
-    const int64_t  n_batches  = (a.elem_count + Cfg::EW - 1) / Cfg::EW;
-    const int64_t  max_blocks = int64_t(n_cus) * waves_cu;
-    const unsigned grid       = static_cast< unsigned >(n_batches < max_blocks ? n_batches : max_blocks);
+    if (tune.waves_per_cu > 0)
+        r.waves_cu = tune.waves_per_cu;
+    r.n_batches              = (a.elem_count + Cfg::EW - 1) / Cfg::EW;
+    const int64_t max_blocks = int64_t(r.n_cus) * r.waves_cu;
+    r.grid                   = static_cast< unsigned >(r.n_batches < max_blocks ? r.n_batches : max_blocks);
+    // contiguous eighths of the batches per XCD, where every XCD group gets the same number of persistent workgroups.  Measured
+    // (profiles/r01_kbench_xcd_mapping.log): order 6 gains 1 % and re-fetches less, order 4 loses 11 % (the elements in flight on
+    // one XCD are neighbours: their atomics meet on the same lines) -- hence orders >= 6 only
+    r.xcd_chunk = (P >= 6 && r.grid % 8 == 0 && r.n_batches >= int64_t(r.grid) && r.n_batches < (int64_t(1) << 30)) ? int((r.n_batches + 7) / 8) : 0;
+    r.dynamic   = a.work_counters != nullptr;
+    return 0;
+}
+
+template < typename K, int P, int NQ, bool MULTI >
+int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    using Cfg = FastCfg< K, P, NQ >;
+    if (a.elem_count <= 0)
+        return 0;
+    if (MULTI && a.n_cols < 1)
+    {
+        setError("multi-column element launch without a column count");
+        return -1;
+    }
+    FastRoute r;
+    if (int rc = planSumfactFast< K, P, NQ, MULTI >(a, r))
+        return rc;
+    if (r.generic)
+    {
+        if constexpr (!MULTI)
+            return launchSumfactApply< K, P, NQ, 1, false >(a, kparam_blob, stream);
+        else
+        {
+            for (int c = 0; c < a.n_cols; ++c) // column by column through the generic single-column kernel
+            {
+                ElemArgs ac = a;
+                ac.n_cols   = 1;
+                ac.x        = a.x + a.ldx * c;
+                ac.xg       = a.xg ? a.xg + a.ldxg * c : nullptr;
+                ac.y        = a.y + a.ldy * c;
+                ac.yg       = a.yg ? a.yg + a.ldyg * c : nullptr;
+                if (int rc = launchSumfactApply< K, P, NQ, 1, false >(ac, kparam_blob, stream))
+                    return rc;
+            }
+            return 0;
+        }
+    }
+    K kern{};
+    if (kparam_blob)
+        __builtin_memcpy(&kern, kparam_blob, sizeof(K));
+    decltype(&sumfactFastKernel< K, P, NQ, false, false >) kernel;
+    if constexpr (MULTI) // (no fused energy, no affine variant: plain applies of several columns)
+        kernel = r.split ? sumfactFastKernel< K, P, NQ, true, false, false, true > : sumfactFastKernel< K, P, NQ, false, false, false, true >;
+    else
+        kernel = r.affine ? sumfactFastKernel< K, P, NQ, false, false, true >
+                 : r.energy ? (r.split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
+                            : (r.split ? sumfactFastKernel< K, P, NQ, true, false > : sumfactFastKernel< K, P, NQ, false, false >);
     constexpr TableLayout   TL{P + 1, NQ};
     FastTables< P + 1, NQ > tab;
     const double*           th = a.tables_host;
@@ -1308,20 +1340,12 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
     __builtin_memcpy(tab.eoCt, th + TL.offEoCt(), sizeof tab.eoCt);
     __builtin_memcpy(tab.qw, th + TL.offW(), sizeof tab.qw);
     __builtin_memcpy(tab.qx, th + TL.offX(), sizeof tab.qx);
-    // contiguous eighths per XCD only when every XCD group gets the same number of persistent workgroups
-    static const bool xcd_env   = std::getenv("L3K_FAST_NO_XCD") == nullptr;
-    // measured (profiles/r01_kbench_xcd_mapping.log): order 6 gains 1 % and re-fetches less, order 4 loses 11 % (the
-    // elements in flight on one XCD are neighbours: their atomics meet on the same lines)
-    static const bool xcd_force = std::getenv("L3K_FAST_XCD") != nullptr;
-    const int         xcd_chunk = ((P >= 6 || xcd_force) && xcd_env && grid % 8 == 0 && n_batches >= int64_t(grid) && n_batches < (int64_t(1) << 30))
-                                      ? int((n_batches + 7) / 8)
-                                      : 0;
     if (a.work_counters && hipMemsetAsync(a.work_counters, 0, 8 * 128, stream) != hipSuccess)
     {
         setError("hipMemsetAsync(work counters) failed");
         return -3;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), Cfg::lds, stream, a, kern, n_batches, xcd_chunk, tab);
+    hipLaunchKernelGGL(kernel, dim3(r.grid), dim3(64), Cfg::lds, stream, a, kern, r.n_batches, r.xcd_chunk, tab);
     if (a.energy && a.energy_done)
         ++*a.energy_done;
     const hipError_t err = hipGetLastError();
@@ -1330,6 +1354,25 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
         setError("sumfactFastKernel launch failed: %s", hipGetErrorString(err));
         return -3;
     }
+    return 0;
+}
+// the route of an apply launch as text (l3k_mf_route): which kernel template, which variant, how it is launched
+template < typename K, int P, int NQ >
+int describeSumfactFast(const ElemArgs& a, char* buf, size_t n)
+{
+    using Cfg = FastCfg< K, P, NQ >;
+    FastRoute r;
+    const bool multi = Cfg::multi_column && a.n_cols > 1;
+    if (int rc = multi ? planSumfactFast< K, P, NQ, Cfg::multi_column >(a, r) : planSumfactFast< K, P, NQ, false >(a, r))
+        return rc;
+    if (r.generic)
+        return describeSumfactApply< K, P, NQ, 1 >(a, buf, n);
+    std::snprintf(buf, n,
+                  "sumfactFastKernel<p=%d,nq=%d,U=%d,F=%d>%s%s%s%s: one wave per %d element(s), %d of 64 lanes, %zu B LDS/wave, "
+                  "%d waves/CU x %d CUs = grid %u, %s batches%s",
+                  P, NQ, Cfg::U, Cfg::F, r.affine ? " affine" : "", r.energy ? " energy" : "", r.split ? " split-ghost" : "",
+                  r.multi ? " multi-column" : "", Cfg::EW, Cfg::EW * Cfg::TEAM, size_t(Cfg::lds), r.waves_cu, r.n_cus, r.grid,
+                  r.dynamic ? "dynamic" : "static", r.xcd_chunk ? ", XCD-chunked" : "");
     return 0;
 }
 template < typename K, int P, int NQ >

@@ -37,14 +37,15 @@ using i64 = int64_t;
 // reference takes whatever order the mesh generator / METIS gives); measured on MI355X (profiles/r01_kbench_brick_sweep.log,
 // 64^3 elements): power-of-two edges alias -- the node rows that the ~1800 resident waves touch at the same time are then
 // a power-of-two apart in HBM -- and cost 5 % at order 6 (edge 4: 15.9 ns per element, 6: 15.1) and 27 % at order 4
-// (edge 4: 6.9, 12: 5.0).  Default: 6 for orders >= 5, 12 below (more elements per wave there); L3K_MESH_BRICK overrides.
+// (edge 4: 6.9, 12: 5.0).  Hence 6 for orders >= 5, 12 below (more elements per wave there).  (The sweep was run with builds
+// that define L3K_MESH_BRICK: tools/brick_sweep.sh.)
 int brickEdge(int order)
 {
-    static const int env = [] {
-        const char* e = std::getenv("L3K_MESH_BRICK");
-        return e ? std::atoi(e) : 0;
-    }();
-    return env > 0 ? env : (order >= 5 ? 6 : 12);
+#ifdef L3K_MESH_BRICK
+    return L3K_MESH_BRICK;
+#else
+    return order >= 5 ? 6 : 12;
+#endif
 }
 
 struct TypeTable // homed non-internal nodes of an element whose low-boundary flags are (fx, fy, fz)

@@ -109,6 +109,10 @@ struct l3k_ctx
     // bitwise-reproducible mode (L3K_DETERMINISTIC=1 or l3k_ctx_set_deterministic): element launches go colour by colour
     // (no two elements of a launch share a node), so every row of y receives its contributions in a fixed order
     bool        deterministic = false;
+    // l3k_ctx_set_reference_z0: matrix-free applies hand domain kernels Point{x, y, 0.} as the reference's hex sum-factorisation
+    // path does (algsys/SumFactorization.hpp:732); default: the true point (what its local-element path passes)
+    bool        reference_z0 = false;
+    l3k_tuning  tune = l3k::dev::defaultTuning(); // launch-route settings (the environment is read once, in l3k_ctx_create)
     double*     red_ws = nullptr; // per-block partial sums of the PCG dot products (cg_blocks * 2 doubles)
     uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes) + one more line:
     // the counter of l3k_assembled_scatter's entries outside the graph (no allocation per call)

@@ -8,6 +8,8 @@
 
 #include "l3k/kernel_interface.hpp"
 
+#include <cmath>
+
 namespace l3k::kernels
 {
 // benchmarks/Diffusion3D.hpp:50-79 (== benchmarks/Kernels.hpp:85-113, tests/Kernels.hpp:55-81 with s = 0)
@@ -120,6 +122,101 @@ struct AdvDiff3D
         Az(5, 1) = 1.;
         Ax(6, 2) = 1.;
         Ay(6, 1) = -1.;
+    }
+};
+
+// Domain kernel whose operators AND rhs read the space-time point (synthetic; the reference's examples do:
+// examples/03-advection-2D/source.cpp:52-66 takes the velocity from point.space.y(), examples/04-periodic-bc/source.cpp:88-89
+// reads point.time): Diffusion3D with k(x,t) = k (1 + 0.3 sin(x + 2y + 3z + t)), -(1 + 0.2 cos(z - t)) instead of -1 on the
+// flux rows and the source s (1 + x y - z t / 2)
+struct Diffusion3DPoint
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 7, .n_unknowns = 4};
+    double                        k = 1., s = 1.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [field_vals, field_ders, point] = in;
+        const double x = point.space.x(), y = point.space.y(), z = point.space.z(), t = point.time;
+        const double kv = k * (1. + 0.3 * sin(x + 2. * y + 3. * z + t));
+        const double c  = -(1. + 0.2 * cos(z - t));
+
+        auto& [operators, rhs] = out;
+        auto& [A0, Ax, Ay, Az] = operators;
+        Ax(0, 1) = -kv;
+        Ay(0, 2) = -kv;
+        Az(0, 3) = -kv;
+        rhs[0]   = s * (1. + x * y - 0.5 * z * t);
+        A0(1, 1) = c;
+        Ax(1, 0) = 1.;
+        A0(2, 2) = c;
+        Ay(2, 0) = 1.;
+        A0(3, 3) = c;
+        Az(3, 0) = 1.;
+        Ay(4, 3) = 1.;
+        Az(4, 2) = -1.;
+        Ax(5, 3) = -1.;
+        Az(5, 1) = 1.;
+        Ax(6, 2) = 1.;
+        Ay(6, 1) = -1.;
+    }
+};
+
+// Scalar advection, one unknown: the 3-D analogue of examples/04-periodic-bc/source.cpp:60-75 (BDF3: the three fields are the
+// solution at the previous time steps) with the point-dependent velocity of examples/03-advection-2D/source.cpp:52-66
+struct Advection3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1, .n_unknowns = 1, .n_fields = 3};
+    static constexpr bool         field_derivatives = false; // the history enters by value only
+    double                        dt = .02;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [field_vals, field_ders, point] = in;
+        const double y_scaled = point.space.y() * 2. - 1., z_scaled = point.space.z() * 2. - 1.;
+        const double vx = (1. - y_scaled * y_scaled) * (1. - .5 * z_scaled * z_scaled); // parabolic profiles
+        const double vy = .25 * point.space.x();
+        const double vz = -.125;
+
+        constexpr double bdf_leading_coef = 11. / 6.;
+        constexpr double bdf_coefs[3]     = {3., -1.5, 1. / 3.};
+
+        auto& [operators, rhs] = out;
+        auto& [A0, A1, A2, A3] = operators;
+        A0(0, 0) = bdf_leading_coef;
+        A1(0, 0) = vx * dt;
+        A2(0, 0) = vy * dt;
+        A3(0, 0) = vz * dt;
+        rhs[0]   = field_vals[0] * bdf_coefs[0] + field_vals[1] * bdf_coefs[1] + field_vals[2] * bdf_coefs[2];
+    }
+};
+
+// Div-curl system (synthetic; an odd number of unknowns): a(x) div u = f, curl u = omega, a zeroth-order coupling on row 1
+struct DivCurl3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 4, .n_unknowns = 3};
+    double                        f = 1.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const double a         = 1. + .5 * in.point.space.x() * in.point.space.z();
+        auto& [operators, rhs] = out;
+        auto& [A0, Ax, Ay, Az] = operators;
+        Ax(0, 0) = a;
+        Ay(0, 1) = a;
+        Az(0, 2) = a;
+        rhs[0]   = f;
+        Ay(1, 2) = 1.;
+        Az(1, 1) = -1.;
+        Az(2, 0) = 1.;
+        Ax(2, 2) = -1.;
+        Ax(3, 1) = 1.;
+        Ay(3, 0) = -1.;
+        A0(1, 0) = .1 * in.point.space.y();
+        rhs[1]   = .5;
     }
 };
 
@@ -264,7 +361,10 @@ struct Unit3D
     X(0, ::l3k::kernels::Diffusion3D, "diffusion3d")                                                                   \
     X(1, ::l3k::kernels::Diffusion3DVar, "diffusion3d_var")                                                            \
     X(4, ::l3k::kernels::AdvDiff3D, "advdiff3d")                                                                       \
-    X(8, ::l3k::kernels::Mass3D, "mass3d")
+    X(8, ::l3k::kernels::Mass3D, "mass3d")                                                                             \
+    X(10, ::l3k::kernels::Diffusion3DPoint, "diffusion3d_point")                                                       \
+    X(11, ::l3k::kernels::Advection3D, "advection3d")                                                                  \
+    X(12, ::l3k::kernels::DivCurl3D, "divcurl3d")
 
 // boundary equation kernels (ids continue the numbering above; 5 is the 2-D adiabatic kernel of the CPU oracle)
 #define L3K_FOR_EACH_BOUNDARY_KERNEL(X)                                                                                \
@@ -300,7 +400,17 @@ struct Unit3D
     X(::l3k::kernels::AdvDiff3D, 2, 3, 2)                                                                              \
     X(::l3k::kernels::AdvDiff3D, 4, 5, 1)                                                                              \
     X(::l3k::kernels::Mass3D, 3, 7, 1)                                                                                 \
-    X(::l3k::kernels::Mass3D, 2, 3, 1)
+    X(::l3k::kernels::Mass3D, 2, 3, 1)                                                                                 \
+    X(::l3k::kernels::Diffusion3DPoint, 2, 3, 1)                                                                       \
+    X(::l3k::kernels::Diffusion3DPoint, 2, 5, 1)                                                                       \
+    X(::l3k::kernels::Diffusion3DPoint, 4, 5, 1)                                                                       \
+    X(::l3k::kernels::Diffusion3DPoint, 6, 7, 1)                                                                       \
+    X(::l3k::kernels::Advection3D, 2, 3, 1)                                                                            \
+    X(::l3k::kernels::Advection3D, 4, 5, 1)                                                                            \
+    X(::l3k::kernels::Advection3D, 6, 7, 1)                                                                            \
+    X(::l3k::kernels::DivCurl3D, 2, 3, 1)                                                                              \
+    X(::l3k::kernels::DivCurl3D, 4, 5, 1)                                                                              \
+    X(::l3k::kernels::DivCurl3D, 6, 7, 1)
 
 #define L3K_FOR_EACH_BOUNDARY_INSTANCE(X)                                                                              \
     X(::l3k::kernels::Adiabatic3D, 2, 3, 1)                                                                            \

@@ -9,6 +9,7 @@ Vectors are torch tensors of shape (ncols, n_owned_dofs), i.e. column-major [row
 only -- the host-view layout of the Tpetra multivectors of the reference.  torch is plumbing here (device memory,
 streams); all compute goes through libl3k.so.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -20,6 +21,9 @@ KERNEL_DIFFUSION3D = 0
 KERNEL_DIFFUSION3D_VAR = 1
 KERNEL_ADVDIFF3D = 4
 KERNEL_MASS3D = 8  # A0 = I: known answers for w * detJ
+KERNEL_DIFFUSION3D_POINT = 10  # operators and rhs read point.space.{x,y,z} and point.time
+KERNEL_ADVECTION3D = 11  # scalar BDF3 advection, U = E = 1, F = 3, velocity from the point
+KERNEL_DIVCURL3D = 12  # div-curl system, U = 3, E = 4
 KERNEL_ADIABATIC3D = 6  # boundary equation kernels
 KERNEL_ROBIN3D = 7
 KERNEL_NORMALFLUX3D = 9  # boundary kernel with derivative operators (A1..A3)
@@ -215,6 +219,36 @@ class Context:
     def set_deterministic(self, on=True):
         """Bitwise-reproducible element launches (colour by colour) for the meshes created from now on."""
         check(capi.load().l3k_ctx_set_deterministic(self._h, int(bool(on))))
+
+    def set_reference_z0(self, on=True):
+        """Applies pass Point{x, y, 0.} to domain kernels as the reference's hex sum-factorisation path does
+        (algsys/SumFactorization.hpp:732); default off: the true point (l3k_ctx_set_reference_z0 in include/l3k.h)."""
+        check(capi.load().l3k_ctx_set_reference_z0(self._h, int(bool(on))))
+
+    def get_tuning(self):
+        """The context's launch-route settings as a dict (l3k_tuning in include/l3k.h)."""
+        t = capi.Tuning()
+        check(capi.load().l3k_ctx_get_tuning(self._h, C.byref(t)))
+        return {name: getattr(t, name) for name, _ in capi.Tuning._fields_}
+
+    def set_tuning(self, **fields):
+        t = capi.Tuning()
+        check(capi.load().l3k_ctx_get_tuning(self._h, C.byref(t)))
+        for name, value in fields.items():
+            if name not in dict(capi.Tuning._fields_):
+                raise L3KError(f"l3k_tuning has no field {name!r}")
+            setattr(t, name, int(value))
+        check(capi.load().l3k_ctx_set_tuning(self._h, C.byref(t)))
+
+    @contextlib.contextmanager
+    def tuning(self, **fields):
+        """with ctx.tuning(generic_below=0): ...  -- the settings inside the block, the previous ones afterwards."""
+        before = self.get_tuning()
+        self.set_tuning(**fields)
+        try:
+            yield self
+        finally:
+            self.set_tuning(**before)
 
     def synchronize(self):
         check(capi.load().l3k_ctx_synchronize(self._h))
@@ -463,6 +497,13 @@ class MatrixFreeSystem:
 
     def set_time(self, t):
         check(capi.load().l3k_mf_set_time(self._h, float(t)))
+
+    def route(self, which=2, ncols=1, with_energy=False):
+        """One line naming the kernel (template, variant, lanes, LDS, grid) the element launch of apply_elems(which, ...,
+        ncols columns) takes right now -- decided by the launcher's own code (l3k_mf_route)."""
+        buf = C.create_string_buffer(512)
+        check(capi.load().l3k_mf_route(self._h, which, ncols, int(with_energy), buf, len(buf)))
+        return buf.value.decode()
 
     @staticmethod
     def _cols(t):

@@ -22,6 +22,8 @@
 namespace
 {
 thread_local std::string g_err;
+// orc_mf_apply passes z = 0 to domain kernels, as the reference's hex sum-factorisation path does (D8); default: the true z
+std::atomic< bool >      g_reference_z0{false};
 int                      fail(int code, const char* msg)
 {
     g_err = msg;
@@ -358,6 +360,124 @@ void kMass3D(const KIn&, KOut& o)
     o.f(1)        = 2.;
 }
 
+// Domain kernel whose operators AND rhs read the space-time point (synthetic; the reference's examples do:
+// examples/03-advection-2D/source.cpp:52-66 takes the velocity from point.space.y(), examples/04-periodic-bc/source.cpp:88-89
+// reads point.time): Diffusion3D with k(x,t) = k0 (1 + 0.3 sin(x + 2y + 3z + t)), a reaction-like A0 entry
+// -(1 + 0.2 cos(z - t)) on the flux rows and the source s0 (1 + x y - 0.5 z t).  kp = {k0, s0}
+void kDiffusion3DPoint(const KIn& in, KOut& o)
+{
+    const double k0 = in.kp ? in.kp[0] : 1., s0 = in.kp ? in.kp[1] : 1.;
+    const double k  = k0 * (1. + 0.3 * std::sin(in.x + 2. * in.y + 3. * in.z + in.t));
+    const double c  = -(1. + 0.2 * std::cos(in.z - in.t));
+    o.op(1, 0, 1)   = -k;
+    o.op(2, 0, 2)   = -k;
+    o.op(3, 0, 3)   = -k;
+    o.f(0)          = s0 * (1. + in.x * in.y - 0.5 * in.z * in.t);
+    o.op(0, 1, 1)   = c;
+    o.op(1, 1, 0)   = 1.;
+    o.op(0, 2, 2)   = c;
+    o.op(2, 2, 0)   = 1.;
+    o.op(0, 3, 3)   = c;
+    o.op(3, 3, 0)   = 1.;
+    o.op(2, 4, 3)   = 1.;
+    o.op(3, 4, 2)   = -1.;
+    o.op(1, 5, 3)   = -1.;
+    o.op(3, 5, 1)   = 1.;
+    o.op(1, 6, 2)   = 1.;
+    o.op(2, 6, 1)   = -1.;
+}
+// Scalar advection, U = E = 1, F = 3: the 3-D analogue of examples/04-periodic-bc/source.cpp:60-75 (BDF3 in time: the three
+// fields are the solution at the previous steps) with the point-dependent velocity of examples/03-advection-2D/source.cpp:52-66
+// (parabolic profile in y, here times a profile in z).  kp = {dt}
+void kAdvection3D(const KIn& in, KOut& o)
+{
+    const double dt = in.kp ? in.kp[0] : .02;
+    const double ys = in.y * 2. - 1., zs = in.z * 2. - 1.;
+    const double vx = (1. - ys * ys) * (1. - .5 * zs * zs), vy = .25 * in.x, vz = -.125;
+    o.op(0, 0, 0)   = 11. / 6.;
+    o.op(1, 0, 0)   = vx * dt;
+    o.op(2, 0, 0)   = vy * dt;
+    o.op(3, 0, 0)   = vz * dt;
+    o.f(0)          = 3. * in.fv[0] - 1.5 * in.fv[1] + in.fv[2] / 3.;
+}
+// Div-curl system, U = 3, E = 4 (synthetic; an odd number of unknowns): div u = f, curl u = omega with a point-dependent
+// weight on the divergence row.  kp = {f}
+void kDivCurl3D(const KIn& in, KOut& o)
+{
+    const double f = in.kp ? in.kp[0] : 1.;
+    const double a = 1. + .5 * in.x * in.z;
+    o.op(1, 0, 0)  = a;
+    o.op(2, 0, 1)  = a;
+    o.op(3, 0, 2)  = a;
+    o.f(0)         = f;
+    o.op(2, 1, 2)  = 1.;
+    o.op(3, 1, 1)  = -1.;
+    o.op(3, 2, 0)  = 1.;
+    o.op(1, 2, 2)  = -1.;
+    o.op(1, 3, 1)  = 1.;
+    o.op(2, 3, 0)  = -1.;
+    o.op(0, 1, 0)  = .1 * in.y; // (a zeroth-order coupling, so that A0 is exercised on an odd number of unknowns)
+    o.f(1)         = .5;
+}
+// benchmarks/Kernels.hpp:3-65: linearised incompressible Navier-Stokes in velocity-pressure-vorticity form, U = 7 (u, v, w, p,
+// ox, oy, oz), E = 8, F = 7 (the same seven quantities of the previous iterate, values and derivatives); Re^-1 = 1e-3
+void kNS3D(const KIn& in, KOut& o)
+{
+    const double  u = in.fv[0], v = in.fv[1], w = in.fv[2];
+    const double *dx = in.fd[0], *dy = in.fd[1], *dz = in.fd[2];
+    const double  ux = dx[0], vx = dx[1], wx = dx[2], uy = dy[0], vy = dy[1], wy = dy[2], uz = dz[0], vz = dz[1], wz = dz[2];
+    constexpr double Re_inv = 1e-3;
+    o.op(0, 0, 0) = ux;
+    o.op(0, 0, 1) = uy;
+    o.op(0, 0, 2) = uz;
+    o.op(0, 1, 0) = vx;
+    o.op(0, 1, 1) = vy;
+    o.op(0, 1, 2) = vz;
+    o.op(0, 2, 0) = wx;
+    o.op(0, 2, 1) = wy;
+    o.op(0, 2, 2) = wz;
+    o.op(0, 3, 4) = 1.;
+    o.op(0, 4, 5) = 1.;
+    o.op(0, 5, 6) = 1.;
+
+    o.op(1, 0, 0) = u;
+    o.op(1, 0, 3) = 1.;
+    o.op(1, 1, 1) = u;
+    o.op(1, 1, 6) = -Re_inv;
+    o.op(1, 2, 2) = u;
+    o.op(1, 2, 5) = Re_inv;
+    o.op(1, 4, 2) = -1.;
+    o.op(1, 5, 1) = 1.;
+    o.op(1, 6, 0) = 1.;
+    o.op(1, 7, 4) = 1.;
+
+    o.op(2, 0, 0) = v;
+    o.op(2, 0, 3) = 1.;
+    o.op(2, 0, 6) = Re_inv;
+    o.op(2, 1, 1) = v;
+    o.op(2, 2, 2) = v;
+    o.op(2, 2, 4) = -Re_inv;
+    o.op(2, 3, 2) = 1.;
+    o.op(2, 5, 0) = -1.;
+    o.op(2, 6, 1) = 1.;
+    o.op(2, 7, 5) = 1.;
+
+    o.op(3, 0, 0) = w;
+    o.op(3, 0, 3) = 1.;
+    o.op(3, 0, 5) = -Re_inv;
+    o.op(3, 1, 1) = w;
+    o.op(3, 1, 4) = Re_inv;
+    o.op(3, 2, 2) = w;
+    o.op(3, 3, 1) = -1.;
+    o.op(3, 4, 0) = 1.;
+    o.op(3, 6, 2) = 1.;
+    o.op(3, 7, 6) = 1.;
+
+    o.f(0) = u * ux + v * uy + w * uz;
+    o.f(1) = u * vx + v * vy + w * vz;
+    o.f(2) = u * wx + v * wy + w * wz;
+}
+
 struct KernelEntry
 {
     KParams kp;
@@ -375,7 +495,11 @@ const KernelEntry* getKernel(int id)
                                         {{3, 1, 4, 0}, kAdiabatic3D, true},
                                         {{3, 1, 4, 0}, kRobin3D, true},
                                         {{3, 2, 2, 0}, kMass3D},
-                                        {{3, 1, 4, 0}, kNormalFlux3D, true}};
+                                        {{3, 1, 4, 0}, kNormalFlux3D, true},
+                                        {{3, 7, 4, 0}, kDiffusion3DPoint},
+                                        {{3, 1, 1, 3}, kAdvection3D},
+                                        {{3, 4, 3, 0}, kDivCurl3D},
+                                        {{3, 8, 7, 7}, kNS3D}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];
@@ -1619,6 +1743,12 @@ int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts,
     return orc_diag_rhs_local_side(-1, kernel_id, p, nq, R, verts, node_fields, kparams, time, n_dir, dir_inds, dir_vals, diag, rhs);
 }
 
+int orc_set_reference_z0(int on)
+{
+    g_reference_z0 = on != 0;
+    return 0;
+}
+
 int orc_apply_sumfact(int kernel_id, int p, int nq, int R, int odd_even, int pass_true_z, const double* verts,
                       const double* node_fields, const double* kparams, double time, const double* x, double* y)
 {
@@ -1665,7 +1795,8 @@ int orc_mf_apply(const orc_mesh* m, int kernel_id, const double* kparams, double
         for (int r = 0; r < R; ++r)
             for (int64_t i = 0; i < n_local_dofs; ++i)
                 y[i + ldy * r] = beta == 0. ? 0. : y[i + ldy * r] * beta;
-    const SumFactCtx ctx{k, m->p, m->nq, R, odd_even != 0, true};
+    // true z unless orc_set_reference_z0(1): then the reference's z = 0 of evalAtHexQPs (SumFactorization.hpp:732, D8)
+    const SumFactCtx ctx{k, m->p, m->nq, R, odd_even != 0, !g_reference_z0.load()};
     const bool       atomic = nthreads > 1;
     parallelFor(e_begin, e_end, nthreads, [&](int64_t b, int64_t e, int) {
         std::vector< double > fill(static_cast< size_t >(N) * (nops + F)), res(static_cast< size_t >(N) * nops);

@@ -36,7 +36,15 @@ enum
     /* boundary equation kernels (the input carries the outward normal) */
     ORC_KERNEL_ADIABATIC2D     = 5, /* tests/Kernels.hpp:120-128: q.n = 0                                            */
     ORC_KERNEL_ADIABATIC3D     = 6, /* 3-D twin                                                                      */
-    ORC_KERNEL_ROBIN3D         = 7  /* synthetic: q.n + h T = h T_inf, kp = {h, T_inf}                               */
+    ORC_KERNEL_ROBIN3D         = 7, /* synthetic: q.n + h T = h T_inf, kp = {h, T_inf}                               */
+    ORC_KERNEL_MASS3D          = 8, /* A0 = I, rhs = (1, 2): pins w * detJ                                           */
+    ORC_KERNEL_NORMALFLUX3D    = 9, /* boundary kernel with derivative operators A1..A3                              */
+    /* domain kernels that read the space-time point (examples/03-advection-2D/source.cpp:52-66,
+     * examples/04-periodic-bc/source.cpp:60-95 do) and kernels with an odd number of unknowns */
+    ORC_KERNEL_DIFFUSION3D_POINT = 10, /* Diffusion3D with k, A0 and s functions of (x, y, z, t); kp = {k0, s0}    */
+    ORC_KERNEL_ADVECTION3D       = 11, /* scalar BDF3 advection, U = E = 1, F = 3, velocity from the point; kp = {dt} */
+    ORC_KERNEL_DIVCURL3D         = 12, /* div-curl system, U = 3, E = 4; kp = {f}                                   */
+    ORC_KERNEL_NS3D              = 13  /* benchmarks/Kernels.hpp:3-65: U = 7, E = 8, F = 7                          */
 };
 /* residual kernels for integrals / L2 norms (fields are the kernel's n_fields inputs) */
 enum
@@ -106,6 +114,10 @@ int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts,
  * of the reference's z = 0 (algsys/SumFactorization.hpp:732). */
 int orc_apply_sumfact(int kernel_id, int p, int nq, int R, int odd_even, int pass_true_z, const double* verts,
                       const double* node_fields, const double* kparams, double time, const double* x, double* y);
+/* process-wide switch for orc_mf_apply: on != 0 -> domain kernels see z = 0 as in the reference's evalAtHexQPs
+ * (algsys/SumFactorization.hpp:732); default 0 -> the true z.  orc_mf_diag_rhs and the local-element functions always
+ * pass the true z (algsys/AssembleLocalSystem.hpp:229-230). */
+int orc_set_reference_z0(int on);
 
 /* ---- mesh-level matrix-free operator (one rank) ------------------------------------------------------------ */
 typedef struct

@@ -94,15 +94,64 @@ def tables(p, nq):
 
 # ---------------------------------------------------------------- kernels (restated; ids as oracle.h)
 def kernel_params(kid):
-    return {0: (3, 7, 4, 0), 1: (3, 7, 4, 1), 2: (2, 4, 3, 0), 3: (2, 4, 3, 1), 4: (3, 7, 4, 3)}[kid]
+    return {0: (3, 7, 4, 0), 1: (3, 7, 4, 1), 2: (2, 4, 3, 0), 3: (2, 4, 3, 1), 4: (3, 7, 4, 3),
+            10: (3, 7, 4, 0), 11: (3, 1, 1, 3), 12: (3, 4, 3, 0), 13: (3, 8, 7, 7)}[kid]
 
 
-def eval_kernel(kid, fv, fd, R, kparams=None):
-    """Returns A [D+1,E,U], rhs [E,R].  tests/Kernels.hpp:5-118, benchmarks/Diffusion3D.hpp:51-79."""
+def eval_kernel(kid, fv, fd, R, kparams=None, point=(0.0, 0.0, 0.0), time=0.0):
+    """Returns A [D+1,E,U], rhs [E,R].  tests/Kernels.hpp:5-118, benchmarks/Diffusion3D.hpp:51-79; ids 10-12: the synthetic
+    point / time reading kernels of oracle.h; 13: benchmarks/Kernels.hpp:3-65 (NS3D)."""
     dim, E, U, F = kernel_params(kid)
     A = np.zeros((dim + 1, E, U))
     rhs = np.zeros((E, R))
-    if kid in (0, 1, 4):
+    x, y, z = point
+    if kid == 10:
+        k0, s0 = (1.0, 1.0) if kparams is None else kparams[:2]
+        lam = k0 * (1.0 + 0.3 * np.sin(x + 2 * y + 3 * z + time))
+        c = -(1.0 + 0.2 * np.cos(z - time))
+        rhs[0, 0] = s0 * (1.0 + x * y - 0.5 * z * time)
+        A[1, 0, 1] = A[2, 0, 2] = A[3, 0, 3] = -lam
+        for d in (1, 2, 3):
+            A[0, d, d] = c
+            A[d, d, 0] = 1.0
+        A[2, 4, 3], A[3, 4, 2] = 1.0, -1.0
+        A[1, 5, 3], A[3, 5, 1] = -1.0, 1.0
+        A[1, 6, 2], A[2, 6, 1] = 1.0, -1.0
+    elif kid == 11:
+        dt = 0.02 if kparams is None else kparams[0]
+        ys, zs = 2 * y - 1, 2 * z - 1
+        A[0, 0, 0] = 11.0 / 6.0
+        A[1, 0, 0] = (1 - ys * ys) * (1 - 0.5 * zs * zs) * dt
+        A[2, 0, 0] = 0.25 * x * dt
+        A[3, 0, 0] = -0.125 * dt
+        rhs[0, 0] = 3.0 * fv[0] - 1.5 * fv[1] + fv[2] / 3.0
+    elif kid == 12:
+        f = 1.0 if kparams is None else kparams[0]
+        a = 1.0 + 0.5 * x * z
+        A[1, 0, 0] = A[2, 0, 1] = A[3, 0, 2] = a
+        rhs[0, 0] = f
+        A[2, 1, 2], A[3, 1, 1] = 1.0, -1.0
+        A[3, 2, 0], A[1, 2, 2] = 1.0, -1.0
+        A[1, 3, 1], A[2, 3, 0] = 1.0, -1.0
+        A[0, 1, 0] = 0.1 * y
+        rhs[1, 0] = 0.5
+    elif kid == 13:
+        ri = 1e-3
+        u, v, w = fv[0], fv[1], fv[2]
+        (ux, vx, wx), (uy, vy, wy), (uz, vz, wz) = fd[0][:3], fd[1][:3], fd[2][:3]
+        A[0, 0, :3], A[0, 1, :3], A[0, 2, :3] = [ux, uy, uz], [vx, vy, vz], [wx, wy, wz]
+        A[0, 3, 4] = A[0, 4, 5] = A[0, 5, 6] = 1.0
+        for (d, vel) in ((1, u), (2, v), (3, w)):
+            A[d, 0, 0] = A[d, 1, 1] = A[d, 2, 2] = vel
+            A[d, 0, 3] = 1.0
+        A[1, 1, 6], A[1, 2, 5], A[1, 4, 2], A[1, 5, 1], A[1, 6, 0], A[1, 7, 4] = -ri, ri, -1.0, 1.0, 1.0, 1.0
+        A[2, 0, 6], A[2, 2, 4], A[2, 3, 2], A[2, 5, 0], A[2, 6, 1], A[2, 7, 5] = ri, -ri, 1.0, -1.0, 1.0, 1.0
+        A[3, 0, 5], A[3, 1, 4], A[3, 3, 1], A[3, 4, 0], A[3, 6, 2], A[3, 7, 6] = -ri, ri, -1.0, 1.0, 1.0, 1.0
+        # (benchmarks/Kernels.hpp:27,38,49: the pressure gradient enters the three momentum rows: A1(0,3), A2(0,3), A3(0,3))
+        rhs[0, 0] = u * ux + v * uy + w * uz
+        rhs[1, 0] = u * vx + v * vy + w * vz
+        rhs[2, 0] = u * wx + v * wy + w * wz
+    elif kid in (0, 1, 4):
         if kid == 0:
             k, s = (1.0, 1.0) if kparams is None else kparams[:2]
             lam = k
@@ -164,7 +213,7 @@ def phys_point(dim, verts, pt):
     return out
 
 
-def element_B(kid, p, nq, R, verts, node_fields=None, kparams=None):
+def element_B(kid, p, nq, R, verts, node_fields=None, kparams=None, time=0.0):
     """Returns B [nqp, E, Nd], w*detJ [nqp], f [nqp, E, R]; QP order x fastest (order is irrelevant to the sums)."""
     dim, E, U, F = kernel_params(kid)
     verts = np.asarray(verts, dtype=np.float64)
@@ -194,7 +243,7 @@ def element_B(kid, p, nq, R, verts, node_fields=None, kparams=None):
         if F:
             fv = node_fields.T @ phi
             fd = gphi @ node_fields
-        A, rhs = eval_kernel(kid, fv, fd, R, kparams)
+        A, rhs = eval_kernel(kid, fv, fd, R, kparams, phys_point(dim, verts, pt), time)
         Bq = np.einsum("eu,b->ebu", A[0], phi)
         for dd in range(dim):
             Bq += np.einsum("eu,b->ebu", A[dd + 1], gphi[dd])
@@ -207,8 +256,8 @@ def element_B(kid, p, nq, R, verts, node_fields=None, kparams=None):
     return B, wj, fq
 
 
-def assemble(kid, p, nq, R, verts, node_fields=None, kparams=None):
-    B, wj, fq = element_B(kid, p, nq, R, verts, node_fields, kparams)
+def assemble(kid, p, nq, R, verts, node_fields=None, kparams=None, time=0.0):
+    B, wj, fq = element_B(kid, p, nq, R, verts, node_fields, kparams, time)
     nqp, E, Nd = B.shape
     Bw = (B * wj[:, None, None]).reshape(nqp * E, Nd)
     K = Bw.T @ B.reshape(nqp * E, Nd)

@@ -16,6 +16,11 @@ KERNEL_DIFFUSION3D_VAR = 1
 KERNEL_DIFFUSION2D = 2
 KERNEL_DIFFUSION2D_VAR = 3
 KERNEL_ADVDIFF3D = 4
+KERNEL_MASS3D = 8
+KERNEL_DIFFUSION3D_POINT = 10  # operators and rhs read point.space.{x,y,z} and point.time
+KERNEL_ADVECTION3D = 11  # U = E = 1, F = 3
+KERNEL_DIVCURL3D = 12  # U = 3, E = 4
+KERNEL_NS3D = 13  # benchmarks/Kernels.hpp:3-65: U = 7, E = 8, F = 7
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -214,6 +219,11 @@ def apply_sumfact(kid, p, nq, verts, x, node_fields=None, kparams=None, time=0.0
     _chk(lib().orc_apply_sumfact(kid, p, nq, x.shape[1], int(odd_even), int(true_z), _d(verts), _d(nf), _d(kpar),
                                  C.c_double(time), _d(x), _d(y)))
     return y
+
+
+def set_reference_z0(on):
+    """mf_apply passes z = 0 to domain kernels as the reference's evalAtHexQPs does (SumFactorization.hpp:732); default off."""
+    _chk(lib().orc_set_reference_z0(int(bool(on))))
 
 
 class MeshView:

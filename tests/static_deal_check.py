@@ -17,12 +17,14 @@ import oracle_lib as O  # noqa: E402
 from l3ster_amd import system  # noqa: E402
 
 ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+assert ctx.get_tuning()["static_deal"] == 1 and ctx.get_tuning()["generic_below"] == 0  # from the environment, at creation
 worst = 0.0
 for p, ne in ((6, (5, 4, 3)), (4, (7, 5, 3)), (2, (9, 4, 4))):
     U = 4
     part = system.CubePartition(ne, p, perturb=0.1)
     mask = part.dirichlet_mask(U)
     mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), system.KERNEL_DIFFUSION3D, [0.7, 1.0])
+    assert "static batches" in mf.route(), mf.route()
     x = part.synthetic_vector(U)
     y0 = part.synthetic_vector(U, seed=3)
     Y = torch.as_tensor(y0.copy(), device="cuda")

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.l3k_version() == 100
+    assert lib.l3k_version() == 101
 
 
 def test_hand_written_dpp_instructions_have_no_hazards():

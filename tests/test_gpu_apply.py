@@ -323,13 +323,12 @@ def test_operator_properties_at_full_size(ctx, ne, p):
     ys = O.mf_apply(om, 0, x.cpu().numpy().T, kparams=[1.0, 0.0], nthreads=len(os.sched_getaffinity(0)))
     assert rel_err(Ax.cpu().numpy()[0], ys[:, 0]) < 1e-12
     # ... and against the static deal of the same kernel (another route through the element list)
-    os.environ["L3K_FAST_STATIC"] = "1"
-    try:
+    with ctx.tuning(static_deal=1):
+        assert "static batches" in mf.route()
         Ay = torch.empty_like(x)
         mf.apply(x, Ay)
         torch.cuda.synchronize()
-    finally:
-        os.environ.pop("L3K_FAST_STATIC", None)
+    assert "dynamic batches" in mf.route() and "sumfactFastKernel<p=6,nq=7,U=4,F=0>" in mf.route()
     assert (Ay - Ax).norm().item() < 1e-13 * Ax.norm().item()
 
 

@@ -1,5 +1,5 @@
 """GPU parity tests of LocalAssembly (K_e, F_e: the sum-factorised assembly kernel on the FP64 vector pipe by default, the
-dense (W Z)^T Z product on the FP64 matrix cores behind L3K_ASSEMBLE_DENSE=1): HIP path through the C ABI vs the oracle's
+dense (W Z)^T Z product on the FP64 matrix cores behind l3k_tuning::assemble_dense): HIP path through the C ABI vs the oracle's
 assembleLocalSystem restatement and the golden fixtures.  Tolerance: max-norm 1e-12 relative to |K_e|_max (stated fp64
 tolerance)."""
 import numpy as np
@@ -71,9 +71,9 @@ def test_local_assembly_vs_oracle(ctx, kid, ne, p, vo, R, kpar):
     (system.KERNEL_DIFFUSION3D, 1, 7, 1, 1, [1.0, 0.5]),   # n = 8; the dense kernel unless the sum-factorised one fits
     (system.KERNEL_ADVDIFF3D, (2, 1, 1), 4, 1, 1, [0.7, 1.3, 0.5]),  # external fields + the DPP kernels (orders >= 4)
 ])
-def test_diagonal_block_kernel_vs_oracle(ctx, kid, ne, p, vo, R, kpar, monkeypatch):
+def test_diagonal_block_kernel_vs_oracle(ctx, kid, ne, p, vo, R, kpar):
     """The streaming mode forms the diagonal blocks (u' == u) by halves in merged iterations, in a kernel of its own
-    (device/assemble.hpp, BLOCKS == 1 / 2).  L3K_ASM_TWO_LAUNCHES=1 makes the stored mode take the same two kernels: K_e entry by
+    (device/assemble.hpp, BLOCKS == 1 / 2).  l3k_tuning::assemble_two_launches makes the stored mode take the same two kernels: K_e entry by
     entry against the oracle, bitwise symmetric; and the streaming checksum equals the stored matrix's."""
     info = system.kernel_info(kid)
     U, F = info["n_unknowns"], info["n_fields"]
@@ -84,9 +84,8 @@ def test_diagonal_block_kernel_vs_oracle(ctx, kid, ne, p, vo, R, kpar, monkeypat
     fields = np.random.default_rng(2).uniform(-1, 1, (F, part.n_local_nodes)) if F else None
     if F:
         mf.set_fields(dev(fields))
-    monkeypatch.setenv("L3K_ASM_TWO_LAUNCHES", "1")
-    K, _, cs = mf.local_assemble(want_checksum=True)
-    monkeypatch.delenv("L3K_ASM_TWO_LAUNCHES")
+    with ctx.tuning(assemble_two_launches=1):
+        K, _, cs = mf.local_assemble(want_checksum=True)
     _, _, cs_stream = mf.local_assemble(want_K=False, want_F=False, want_checksum=True)
     K1, _, _ = mf.local_assemble()
     torch.cuda.synchronize()
@@ -122,20 +121,17 @@ def test_local_assembly_order6_vs_golden(ctx, golden):
 
 
 @pytest.mark.parametrize("dense", [False, True])
-def test_local_assembly_order6_vs_oracle_entrywise(ctx, dense, monkeypatch):
+def test_local_assembly_order6_vs_oracle_entrywise(ctx, dense):
     """The north-star assembly shape entry by entry: the full 1372 x 1372 K_e and F_e of the default sum-factorised kernel
-    and of the dense MFMA product (L3K_ASSEMBLE_DENSE=1) against the oracle's assembleLocalSystem
+    and of the dense MFMA product (l3k_tuning::assemble_dense) against the oracle's assembleLocalSystem
     (algsys/AssembleLocalSystem.hpp:77-216,234-256) on the reference's distorted test hex and on elements of a perturbed
     mesh; max-norm 1e-12 relative to |K_e|_max."""
-    if dense:
-        monkeypatch.setenv("L3K_ASSEMBLE_DENSE", "1")
-    else:
-        monkeypatch.delenv("L3K_ASSEMBLE_DENSE", raising=False)
     p, U, kpar, kid = 6, 4, [0.7, 1.3], system.KERNEL_DIFFUSION3D
     cases = [(SingleElementMesh(p, HEX), [0]), (system.CubePartition((2, 2, 1), p, perturb=0.2), [0, 3])]
     for part, elems in cases:
         mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U), kid, kpar)
-        K, Fe, _ = mf.local_assemble()
+        with ctx.tuning(assemble_dense=int(dense)):
+            K, Fe, _ = mf.local_assemble()
         torch.cuda.synchronize()
         K, Fe = K.cpu().numpy(), Fe.cpu().numpy()
         for e in elems:
@@ -195,19 +191,12 @@ def test_mass_kernel_pins_weight_times_jacobian(ctx, p, vo):
     assert np.abs(K - K_ref).max() < 1e-12 * np.abs(K_ref).max()
     ones = np.zeros(K.shape[0])
     ones[0::2] = 1.0
-    import os
-    before = os.environ.get("L3K_GENERIC_BELOW")
-    for generic_below in ("0", "1000000"):  # the one-wave kernel and the generic LDS kernel
-        os.environ["L3K_GENERIC_BELOW"] = generic_below
-        try:
+    for generic_below in (0, 1000000):  # the one-wave kernel and the generic LDS kernel
+        with ctx.tuning(generic_below=generic_below):
+            assert ("sumfactApplyKernel" if generic_below else "sumfactFastKernel") in mf.route()
             X, Y = dev(ones[None, :]), dev(np.zeros((1, K.shape[0])))
             mf.apply(X, Y, 1.0, 0.0)
             torch.cuda.synchronize()
-        finally:
-            if before is None:
-                os.environ.pop("L3K_GENERIC_BELOW", None)
-            else:
-                os.environ["L3K_GENERIC_BELOW"] = before
         y = Y.cpu().numpy()[0]
         np.testing.assert_allclose(y, K_ref @ ones, atol=1e-12)
         assert abs(y[0::2].sum() - vol) < 1e-11 and np.abs(y[1::2]).max() < 1e-13
@@ -263,19 +252,17 @@ def _csr_graph(part, dpn, field_inds):
 @pytest.mark.parametrize("mode", ["node_rows", "per_entry", "global"])
 @pytest.mark.parametrize("kid,p,vo,R,kpar", [(system.KERNEL_DIFFUSION3D, 2, 1, 2, [0.7, 1.3]), (system.KERNEL_MASS3D, 3, 2, 1, None),
                                              (system.KERNEL_DIFFUSION3D, 4, 1, 1, [1.0, 1.0])])
-def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, mode, monkeypatch):
+def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, mode, request):
     """a20, scatterLocalSystem + assembleGlobalSystem (algsys/ScatterLocalSystem.hpp:24-54, AssembleGlobalSystem.hpp:20-53)
     on the device: local systems of a 3^3 (2^3 at order 4) distorted mesh from l3k_local_assemble summed into the caller's
     CSR values and the global right-hand sides, in two batches; against the oracle's element systems added into a dense
     global matrix on the host.  Then with skip_dirichlet: the assembled operator equals the matrix-free apply."""
     import scipy.sparse as sp
     # node_rows (default): one wave per (element, row node), one search per entry shared by the node's U rows; per_entry
-    # (L3K_SCATTER_PER_ENTRY=1): the round-2 kernel, a search per entry; global: l3k_assemble_global, the whole pipeline inside
+    # (l3k_tuning::scatter_per_entry): the round-2 kernel, a search per entry; global: l3k_assemble_global, the whole pipeline inside
     # the library (sub-batches of element systems formed on one stream and scattered on another)
-    if mode == "per_entry":
-        monkeypatch.setenv("L3K_SCATTER_PER_ENTRY", "1")
-    else:
-        monkeypatch.delenv("L3K_SCATTER_PER_ENTRY", raising=False)
+    ctx.set_tuning(scatter_per_entry=int(mode == "per_entry"))
+    request.addfinalizer(lambda: ctx.set_tuning(scatter_per_entry=0))
     info = system.kernel_info(kid)
     U = info["n_unknowns"]
     ne = 2 if p == 4 else 3
@@ -336,3 +323,27 @@ def test_assembled_scatter_vs_oracle_dense(ctx, kid, p, vo, R, kpar, mode, monke
         torch.cuda.synchronize()
         want = Af @ x[0] + np.where(mask, x[0], 0.0)
         assert np.linalg.norm(Y.cpu().numpy()[0] - want) < 1e-11 * np.linalg.norm(want)
+
+
+@pytest.mark.parametrize("mode", ["node_rows", "per_entry"])
+def test_rhs_scatter_with_more_than_64_rhs_entries_per_node(ctx, mode):
+    """the per-row-node scatter kernels added F_e with `lane < n_rhs * U` in one 64-lane wave, so with n_rhs * U > 64
+    (here 17 right-hand sides of 4 unknowns) the remaining entries were silently dropped.  F_e only (scatterLocalSystem's
+    atomic rhs adds, algsys/ScatterLocalSystem.hpp:45-52), against a host scatter-add; with skipped Dirichlet rows too."""
+    U, p, R = 4, 2, 17
+    part = system.CubePartition(3, p, perturb=0.1)
+    mask = part.dirichlet_mask(U)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), system.KERNEL_DIFFUSION3D, n_rhs=R)
+    Nd, n = (p + 1) ** 3 * U, part.n_local_nodes * U
+    F = np.random.default_rng(5).uniform(-1, 1, (part.n_elems, R, Nd))
+    dofs = (part.elem_nodes.astype(np.int64)[:, :, None] * U + np.arange(U)[None, None, :]).reshape(part.n_elems, Nd)
+    with ctx.tuning(scatter_per_entry=int(mode == "per_entry")):
+        for skip in (False, True):
+            want = np.zeros((R, n))
+            for r in range(R):
+                np.add.at(want[r], dofs.reshape(-1), F[:, r, :].reshape(-1))
+            if skip:
+                want[:, mask.astype(bool)] = 0.0
+            rhs = torch.zeros((R, n), dtype=torch.float64, device="cuda")
+            mf.assembled_scatter(None, dev(F), None, None, None, rhs, skip_dirichlet=skip)
+            np.testing.assert_allclose(rhs.cpu().numpy(), want, rtol=0, atol=1e-13)

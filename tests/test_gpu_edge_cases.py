@@ -131,7 +131,7 @@ def test_randomised_apply_and_diag_rhs_parity(S, ctx, seed):
     assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-11 and helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-10, (p, nq, ne)
 
 
-def test_small_launch_routing(S, ctx, monkeypatch):
+def test_small_launch_routing(S, ctx):
     """Default routing: a mesh below the small-launch threshold goes through the generic LDS kernel, above it through the
     one-wave-per-element kernel; both agree with the oracle and with each other."""
     import oracle_lib as O
@@ -143,14 +143,12 @@ def test_small_launch_routing(S, ctx, monkeypatch):
     x = part.synthetic_vector(U)
     want = O.mf_apply(helpers.oracle_mesh(part, p + 1, U, np.arange(U), mask), O.KERNEL_DIFFUSION3D, x.T, kparams=[1.0, 1.0])
     out = {}
-    for name, value in (("generic", None), ("fast", "0")):
-        if value is None:
-            monkeypatch.delenv("L3K_GENERIC_BELOW", raising=False)  # product default: 768
-        else:
-            monkeypatch.setenv("L3K_GENERIC_BELOW", value)
-        Y = torch.zeros((1, part.n_local_nodes * U), dtype=torch.float64, device="cuda")
-        mf.apply(torch.as_tensor(x, device="cuda"), Y)
-        out[name] = Y.cpu().numpy()
+    for name, value in (("generic", 1500), ("fast", 0)):  # (1500 = the product default, l3k_tuning::generic_below)
+        with ctx.tuning(generic_below=value):
+            assert ("sumfactApplyKernel" if name == "generic" else "sumfactFastKernel") in mf.route(), mf.route()
+            Y = torch.zeros((1, part.n_local_nodes * U), dtype=torch.float64, device="cuda")
+            mf.apply(torch.as_tensor(x, device="cuda"), Y)
+            out[name] = Y.cpu().numpy()
         assert helpers.rel_err(out[name].T, want) < 1e-12, name
     assert not np.array_equal(out["generic"], out["fast"])  # different kernels: different rounding
 
@@ -185,7 +183,8 @@ def test_ghost_rows_behind_the_owned_rows(S, ctx, p):
 
 
 def test_static_deal_fallback():
-    """L3K_FAST_STATIC=1 (static deal of the batches instead of the per-XCD counters) still agrees with the oracle."""
+    """L3K_FAST_STATIC=1 in the environment of a fresh process (the environment initialises the context's l3k_tuning once, at
+    l3k_ctx_create): the static deal of the batches instead of the per-XCD counters still agrees with the oracle."""
     import os
     import subprocess
     import sys
@@ -323,3 +322,32 @@ def test_deterministic_mode_with_derivative_boundary_kernel(ne):
     wd, wr = np.zeros(mask.size), np.zeros((mask.size, 1), order="F")
     O.bnd_diag_rhs(om, O.KERNEL_NORMALFLUX3D, fe, fs, wd, wr, kparams=kp)
     assert rel_err(drs[0][0].cpu().numpy(), wd) < 1e-12 and rel_err(drs[0][1].cpu().numpy().T, wr) < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_as_typed():
+    """`python bench.py --gpus 2 ...` typed WITHOUT a launcher (it used to exit with "launch with torch.distributed.run"):
+    the script starts its two ranks itself as child processes (l3ster_amd/launch.py), relays rank 0's single JSON line and returns 0.
+    On the one-GPU box under L3K_BENCH_REHEARSAL=1 (both ranks on GPU 0, gloo, host-staged messages); the partitioned apply is
+    checked inside against one rank's apply on the whole mesh."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["L3K_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--ne", "8", "--steps", "2", "--warmup", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # (gloo announces itself on stdout)
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["steps"] == 2
+    assert out["rehearsal_check"]["xAx_and_yy_vs_one_rank_rel"] < 1e-11
+    assert "sumfactFastKernel" in out["roofline"]["kernel"]
+    # a failing rank fails the command (and does not leave the other rank waiting in a collective)
+    env["L3K_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--ne", "8", "--steps", "2", "--warmup", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "rank 1 of 2" in (r.stdout + r.stderr)

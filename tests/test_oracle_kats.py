@@ -179,7 +179,10 @@ def test_k4_odd_even_equals_standard(EO, QO):
 
 # ------------------------------------------------------------------------------------------------ golden fixtures
 CASES = ["hex_p3_diff", "hex_p3_var", "quad_p4_diff", "quad_p4_var", "hex_p4_diff", "hex_p6_diff", "hex_p4_advdiff",
-         "hex_p2_advdiff"]
+         "hex_p2_advdiff",
+         # round 4: kernels reading point.space / point.time (the sum-factorised path is checked with the true z here; the
+         # reference's z = 0 of SumFactorization.hpp:732 in test_reference_z0_is_what_the_sumfact_path_passes), odd U, NS3D
+         "hex_p2_point", "hex_p4_point", "hex_p4_advection", "hex_p2_divcurl", "hex_p2_ns3d"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -189,18 +192,54 @@ def test_oracle_vs_golden(golden, name):
     nf = g.get("node_fields")
     kpar = g.get("kparams")
     scale = np.linalg.norm(g["y"])
-    for fn in (lambda: O.apply_local(kid, p, nq, g["verts"], g["x"], nf, kpar),
-               lambda: O.apply_sumfact(kid, p, nq, g["verts"], g["x"], nf, kpar),
-               lambda: O.apply_sumfact(kid, p, nq, g["verts"], g["x"], nf, kpar, odd_even=True)):
+    t = float(g.get("time", 0.0))
+    for fn in (lambda: O.apply_local(kid, p, nq, g["verts"], g["x"], nf, kpar, time=t),
+               lambda: O.apply_sumfact(kid, p, nq, g["verts"], g["x"], nf, kpar, time=t, true_z=True),
+               lambda: O.apply_sumfact(kid, p, nq, g["verts"], g["x"], nf, kpar, time=t, odd_even=True, true_z=True)):
         assert np.linalg.norm(fn() - g["y"]) < 1e-12 * scale
-    diag, rhs = O.diag_rhs_local(kid, p, nq, R, g["verts"], g["dir_inds"], g["dir_vals"], nf, kpar)
+    diag, rhs = O.diag_rhs_local(kid, p, nq, R, g["verts"], g["dir_inds"], g["dir_vals"], nf, kpar, time=t)
     np.testing.assert_allclose(diag, g["diag"], rtol=1e-12, atol=1e-13)
     assert np.linalg.norm(rhs - g["rhs_lifted"]) < 1e-12 * max(1.0, np.linalg.norm(g["rhs_lifted"]))
     if "K" in g or p <= 4:
-        K, F = O.assemble_local(kid, p, nq, R, g["verts"], nf, kpar)
+        K, F = O.assemble_local(kid, p, nq, R, g["verts"], nf, kpar, time=t)
         np.testing.assert_allclose(F, g["F"], rtol=0, atol=1e-12 * max(1.0, np.abs(g["F"]).max()))
         if "K" in g:
             np.testing.assert_allclose(K, g["K"], rtol=0, atol=1e-12 * np.abs(g["K"]).max())
+
+
+def test_reference_z0_is_what_the_sumfact_path_passes(golden):
+    """evalAtHexQPs hands the kernel Point{x, y, 0.} (algsys/SumFactorization.hpp:732), the local-element path the
+    true point (algsys/AssembleLocalSystem.hpp:229-230).  The oracle's switch reproduces both: with the reference's z = 0 a
+    z-reading kernel gives ANOTHER operator than the local-element path; on an element lying in z in [0, ...] whose kernel
+    does not read z the two agree.  (Element-level statement; the mesh-level switch is orc_set_reference_z0.)"""
+    g = golden("hex_p2_point")
+    kid, p, nq, t = int(g["kid"]), int(g["p"]), int(g["nq"]), float(g["time"])
+    y_true = O.apply_sumfact(kid, p, nq, g["verts"], g["x"], None, g["kparams"], time=t, true_z=True)
+    y_z0 = O.apply_sumfact(kid, p, nq, g["verts"], g["x"], None, g["kparams"], time=t, true_z=False)
+    assert np.linalg.norm(y_true - g["y"]) < 1e-12 * np.linalg.norm(g["y"])
+    assert np.linalg.norm(y_z0 - g["y"]) > 1e-3 * np.linalg.norm(g["y"])  # the divergence is not a rounding effect
+    # z = 0 equals the true-z operator of a kernel evaluated on the element's footprint in the plane z = 0: flatten the
+    # element's point dependence by hand -- same element, kernel evaluated at (x, y, 0) -- through the numpy restatement
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_np as P
+    pp = P.phys_point
+    try:
+        P.phys_point = lambda dim, verts, pt: pp(dim, verts, pt) * np.array([1.0, 1.0, 0.0])
+        K0, _ = P.assemble(kid, p, nq, 1, g["verts"], None, g["kparams"], t)
+    finally:
+        P.phys_point = pp
+    assert np.linalg.norm(y_z0 - K0 @ g["x"]) < 1e-12 * np.linalg.norm(g["y"])
+    # the mesh-level switch
+    from helpers import SingleElementMesh, oracle_mesh
+    om = oracle_mesh(SingleElementMesh(p, g["verts"]), nq, 4, np.arange(4))
+    try:
+        O.set_reference_z0(True)
+        y_mesh = O.mf_apply(om, kid, g["x"], kparams=g["kparams"], time=t)
+    finally:
+        O.set_reference_z0(False)
+    assert np.linalg.norm(y_mesh - y_z0) < 1e-13 * np.linalg.norm(g["y"])
+    assert np.linalg.norm(O.mf_apply(om, kid, g["x"], kparams=g["kparams"], time=t) - y_true) < 1e-13 * np.linalg.norm(g["y"])
 
 
 def test_degenerate_element_is_reported():

@@ -125,21 +125,80 @@ def test_native_pcg_matches_torch_pcg():
 
 
 @pytest.mark.gpu
+def test_pcg_with_zero_preconditioner_entries():
+    """the iteration keeps z = M^-1 r, and r = z / minv was 0 / 0 = NaN on rows where the caller's preconditioner is
+    zero (the common way to freeze constrained dofs; l3k_jacobi_inverse with damping 0).  Such rows are frozen now: x keeps its
+    initial value there and the other rows solve the system restricted to them, A_ff x_f = b_f - A_fc x_c -- checked against the
+    torch-op restatement (solve.cg, which keeps r itself) on that restricted system written out explicitly -- and the single-rank
+    and the partitioned entry points agree."""
+    import torch
+    from l3ster_amd import solve, system
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    p, U = 3, 4
+    part = system.CubePartition(4, p, perturb=0.1)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, part.dirichlet_mask(U)), system.KERNEL_DIFFUSION3D, [1.0, 1.0])
+    diag, rhs = mf.diag_rhs(None)
+    minv = solve.jacobi_inverse_native(ctx, diag)
+    frozen = torch.zeros_like(minv, dtype=torch.bool)
+    frozen[torch.randperm(minv.numel(), generator=torch.Generator().manual_seed(3))[:200].cuda()] = True
+    minv[frozen] = 0.0
+    x0 = torch.as_tensor(part.synthetic_vector(U)[0, :minv.numel()], device="cuda") * 0.1
+    # the restricted system, explicitly: identity on the frozen rows, their columns moved to the right-hand side
+    def apply_restricted(v, out):
+        vf = v.clone()
+        vf[frozen] = 0.0
+        mf.apply(vf[None, :], out[None, :])
+        out[frozen] = v[frozen]
+    xc = torch.zeros_like(x0)
+    xc[frozen] = x0[frozen]
+    b_r = torch.empty_like(x0)
+    mf.apply(xc[None, :], b_r[None, :])
+    b_r = rhs[0] - b_r
+    b_r[frozen] = x0[frozen]
+    minv_r = minv.clone()
+    minv_r[frozen] = 1.0
+    x1 = x0.clone()
+    r1 = solve.cg(apply_restricted, b_r, x1, minv_r, tol=1e-12, residual_scaling="rhs", max_iters=3000)
+    assert r1.converged
+    x2 = x0.clone()
+    r2 = solve.pcg(mf, rhs[0], x2, minv, tol=1e-11, residual_scaling="rhs", throw_on_fail=False, max_iters=3000)
+    assert bool(torch.isfinite(x2).all()) and r2.tol == r2.tol  # no NaN
+    assert torch.equal(x2[frozen], x0[frozen])  # frozen rows keep the initial guess
+    assert r2.converged  # (its residual norm leaves the frozen rows out)
+    assert (x1 - x2).norm().item() < 1e-7 * x1.norm().item()
+
+    class Op:
+        def apply(self, X, Y):
+            mf.apply(X, Y)
+    x3 = x0.clone()
+    r3 = solve.pcg_distributed(Op(), ctx, rhs[0], x3, minv, tol=1e-11, residual_scaling="rhs", throw_on_fail=False, max_iters=3000)
+    assert abs(r3.num_iters - r2.num_iters) <= 1 and (x3 - x2).norm().item() < 1e-9 * x2.norm().item()
+    # damping 0: every row frozen -- nothing moves, nothing is NaN
+    zero = solve.jacobi_inverse_native(ctx, diag, damping=0.0)
+    assert float(zero.abs().max()) == 0.0
+    x4 = x0.clone()
+    r4 = solve.pcg(mf, rhs[0], x4, zero, tol=1e-11, residual_scaling="rhs", throw_on_fail=False, max_iters=10)
+    assert torch.equal(x4, x0) and r4.tol == r4.tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p,ne,fast", [(6, 4, True), (4, 5, True), (2, 6, True), (6, 3, False)])
-def test_apply_energy_equals_dot_product(p, ne, fast, monkeypatch):
+def test_apply_energy_equals_dot_product(p, ne, fast):
     """l3k_mf_apply_energy: y = A x and <x, A x> from the quadrature stage of the element kernel (fast = single-wave route)
     or from the fallback dot product (small mesh on the generic route): both equal the explicit dot product."""
     import torch
     from l3ster_amd import system
-    monkeypatch.setenv("L3K_GENERIC_BELOW", "0" if fast else "1000000")
     U = 4
     ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_tuning(generic_below=0 if fast else 1000000)
     part = system.CubePartition(ne, p, perturb=0.1)
     mask = part.dirichlet_mask(U)
     mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), system.KERNEL_DIFFUSION3D, [0.7, 1.0])
     X = torch.as_tensor(part.synthetic_vector(U), device="cuda")  # non-zero on the Dirichlet rows too
     Y = torch.full_like(X, 3.0)
     S = torch.full((8,), 7.0, dtype=torch.float64, device="cuda")
+    assert ("sumfactFastKernel" in mf.route(with_energy=True) and " energy" in mf.route(with_energy=True)) == fast
     mf.apply_energy(X, Y, S)
     Yr = torch.zeros_like(X)
     mf.apply(X, Yr)

@@ -1,5 +1,5 @@
 """Multi-column apply (n_rhs columns in one pass over the elements) against column-by-column launches of the single-column
-kernel (L3K_COLUMN_BY_COLUMN=1): Diffusion3D, order 6 / 4.   python tools/bench_multicol.py [--ne 48] [--cols 3]"""
+kernel (l3k_tuning::column_by_column): Diffusion3D, order 6 / 4.   python tools/bench_multicol.py [--ne 48] [--cols 3]"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,8 +21,7 @@ mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, part.dirichlet_mask
 X = torch.as_tensor(part.synthetic_vector(U, ncols=a.cols), device="cuda")
 out = {}
 for mode in ("one pass", "column by column"):
-    if mode == "column by column":
-        os.environ["L3K_COLUMN_BY_COLUMN"] = "1"
+    ctx.set_tuning(column_by_column=int(mode == "column by column"))
     Y = torch.zeros_like(X)
     for _ in range(5):
         mf.apply(X, Y, 1.0, 0.0)
@@ -33,7 +32,7 @@ for mode in ("one pass", "column by column"):
     e1.record()
     torch.cuda.synchronize()
     out[mode] = (e0.elapsed_time(e1) / a.steps, Y.clone())
-os.environ.pop("L3K_COLUMN_BY_COLUMN", None)
+ctx.set_tuning(column_by_column=0)
 d = (out["one pass"][1] - out["column by column"][1]).norm().item() / out["column by column"][1].norm().item()
 print(json.dumps({"order": a.order, "ne": a.ne, "cols": a.cols, "ms_one_pass": out["one pass"][0], "ms_column_by_column": out["column by column"][0],
                   "rel_diff": d, "dof_per_s_one_pass": part.n_global_nodes * U * a.cols / (out["one pass"][0] * 1e-3)}))

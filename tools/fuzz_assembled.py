@@ -59,11 +59,9 @@ while time.time() < t_end:
                 ws = int(2 * 8 * (Nd * Nd + Nd + 10000) * rng.integers(1, 4))  # room for one to three elements per half
                 miss = mf.assemble_global(RP, CI, v, rhs, skip_dirichlet=skip, workspace_bytes=ws)
             else:
-                if route == "per_entry":
-                    os.environ["L3K_SCATTER_PER_ENTRY"] = "1"
                 K, Fe, _ = mf.local_assemble()
-                miss = mf.assembled_scatter(K, Fe, RP, CI, v, rhs, skip_dirichlet=skip)
-                os.environ.pop("L3K_SCATTER_PER_ENTRY", None)
+                with ctx.tuning(scatter_per_entry=int(route == "per_entry")):
+                    miss = mf.assembled_scatter(K, Fe, RP, CI, v, rhs, skip_dirichlet=skip)
             assert miss == 0, (miss, case)
             vals[(route, skip)] = (v, rhs)
     torch.cuda.synchronize()
@@ -98,9 +96,8 @@ while time.time() < t_end:
     # checksums are those of the stored matrices; the stored mode through the same two kernels gives the same symmetric matrices
     K, _, _ = mf.local_assemble(want_F=False)
     _, _, cs = mf.local_assemble(want_K=False, want_F=False, want_checksum=True)
-    os.environ["L3K_ASM_TWO_LAUNCHES"] = "1"
-    K2l, _, _ = mf.local_assemble(want_F=False)
-    os.environ.pop("L3K_ASM_TWO_LAUNCHES")
+    with ctx.tuning(assemble_two_launches=1):
+        K2l, _, _ = mf.local_assemble(want_F=False)
     ii = torch.arange(Nd, device="cuda")
     wgt = (1 + (ii[:, None] * 31 + ii[None, :] * 17) % 7).double()
     cs_ref, cs_abs = (K * wgt).sum(dim=(1, 2)), (K.abs() * wgt).sum(dim=(1, 2))

@@ -1,5 +1,8 @@
 #!/bin/bash
-# the PCG with the p pass inside the element kernel's gather (default) vs L3K_PCG_UNFUSED=1 (9 vector passes), same box
+# the PCG with the p pass inside the element kernel's gather (default) vs L3K_PCG_UNFUSED=1 (9 vector passes), same box.
+# The attempt was NOT kept: the switch exists only in a tree with tools/attempts/r03_pcg_p_pass_in_gather.patch applied (to the commit
+# that added the patch: git log -- tools/attempts/r03_pcg_p_pass_in_gather.patch) and rebuilt.  On HEAD both legs would run the same code.
+grep -rq L3K_PCG_UNFUSED l3ster_amd/csrc || { echo "apply tools/attempts/r03_pcg_p_pass_in_gather.patch and rebuild first: HEAD has no L3K_PCG_UNFUSED switch" >&2; exit 1; }
 export TMPDIR=/tmp
 for rep in 1 2; do
   for v in 0 1; do
