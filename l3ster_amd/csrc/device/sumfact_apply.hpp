@@ -25,6 +25,10 @@ constexpr int cmax(int a, int b)
 {
     return a > b ? a : b;
 }
+constexpr int cmin(int a, int b)
+{
+    return a < b ? a : b;
+}
 
 // One family of 1-D contractions along AXIS of an array with dims (DI, DJ, DK) (i fastest), NOPS arrays `op_stride`
 // apart: out[q] (+)= sum_b in[b] * W(b, q), W(b,q) = TRANS ? Mat[q*NIN + b] : Mat[b*NOUT + q].

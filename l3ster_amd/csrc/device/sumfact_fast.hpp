@@ -97,6 +97,21 @@ __device__ __forceinline__ void sweepEO(const double (&in)[NIN], double (&out)[N
     }
 }
 
+// the second field of a field group: swept where the group is fully used, zeros where it is the padding of an odd field count
+// (`live` is a compile-time constant after unrolling: no branch in the code)
+template < int NIN, int NOUT, bool ANTI, bool ACC >
+__device__ __forceinline__ void sweepEOSecond(bool live, const double (&in)[NIN], double (&out)[NOUT], const double* __restrict__ eo)
+{
+    if (live)
+        sweepEO< NIN, NOUT, ANTI, ACC >(in, out, eo);
+    else if constexpr (!ACC)
+    {
+#pragma unroll
+        for (int q = 0; q < NOUT; ++q)
+            out[q] = 0.;
+    }
+}
+
 // the 1-D tables the fast kernel needs, passed BY VALUE in the kernel arguments: kernarg memory is read with scalar
 // loads (s_load), so every coefficient is an SGPR operand of the FMAs and costs no vector-memory or LDS traffic
 template < int N1, int NQ >
@@ -205,6 +220,19 @@ __device__ __forceinline__ uint32_t dirichletBits(const uint8_t* __restrict__ ma
     }
 }
 
+// Waves per SIMD the single-wave kernel is compiled for (its register budget: 256 VGPRs at 2, 168 at 3).  A 4-unknown, 7-equation
+// kernel needs 252 registers at order 6 (three waves per SIMD spill); a SCALAR kernel holds a quarter of the pencil
+// state (order 6: 144 registers) and runs three waves per SIMD without spills.  A functor may say so itself
+// (static constexpr int waves_per_simd = 2 or 3).
+template < typename K, int NQ_, int NFD >
+constexpr int kernelWavesPerSimd()
+{
+    if constexpr (requires { K::waves_per_simd; })
+        return K::waves_per_simd;
+    else
+        return K::params.n_unknowns == 1 && NQ_ * NFD <= 36 ? 3 : L3K_FAST_MIN_WAVES;
+}
+
 template < typename K, int P, int NQ >
 struct FastCfg
 {
@@ -230,12 +258,15 @@ struct FastCfg
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D + SLOT_B;
     static constexpr int    SG       = (64 / EW) / U * U; // lanes that scatter one element (the team's lanes + helpers): a multiple of U
     static constexpr int    NSH      = NN - (N1 - 2) * (N1 - 2) * (N1 - 2); // nodes on the element's shell
-    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUFB_D && U % 2 == 0 && N1 <= 8 && SG >= U;
+    // (any number of unknowns: an odd U leaves the second half of its last field group to the first external field, or unused)
+    static constexpr bool   feasible = TEAM <= 64 && lds <= 64 * 1024 && NF * cmax(N1, NQ) <= 64 && NN * U <= BUFB_D && N1 <= 8 && SG >= U;
     // resident single-wave workgroups per CU by LDS capacity; with at most one per SIMD the wave may use all 512
     // registers (VGPR + AGPR) of its SIMD lane instead of spilling to scratch (order 7: 33 KB of LDS per wave)
     static constexpr int waves_by_lds = int((160 * 1024) / (lds > 0 ? lds : 1));
     // (three waves per SIMD for the small-LDS shapes was tried: 168 registers, spills, order 4 5.1 -> 7.5 ns per element)
-    static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : L3K_FAST_MIN_WAVES;
+    static constexpr int min_waves    = waves_by_lds <= 4 ? 1 : (waves_by_lds <= 8 ? cmin(2, kernelWavesPerSimd< K, NQ, NF + DF >()) : kernelWavesPerSimd< K, NQ, NF + DF >());
+    // (the multi-column variant carries the column loop's state on top: two waves per SIMD at most)
+    static constexpr int wavesPerSimd(bool multi) { return multi ? cmin(2, min_waves) : min_waves; }
     // field groups whose LDS reads are issued together in the LDS -> LDS stages (2 * N1 doubles of registers per extra group).
     // (order 4 at three waves per SIMD, 168 registers, was tried again with read_block = 1: still 34 spilled registers.)
     static constexpr int read_block   = NG;
@@ -258,7 +289,7 @@ struct FastCfg
 // once per column (the geometry is recomputed: no registers to keep 343 Jacobians).  A variant of its own, so that the
 // single-column kernel's code and register allocation stay what they are.
 template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false >
-__global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
+__global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
     using Cfg = FastCfg< K, P, NQ >;
@@ -406,13 +437,22 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
         {
             const int64_t node = ids[k];
             const double* p    = !SPLIT || node < n_owned_nodes ? ax + node * U : axg + (node - n_owned_nodes) * U;
-#pragma unroll
-            for (int hh = 0; hh < U / 2; ++hh)
+            if constexpr (U % 2 == 0)
             {
-                const double2 t = (L3K_DBG(a) & 2) ? make_double2(1e-9 * double(node), 1e-9)
-                                              : *reinterpret_cast< const double2* >(p + 2 * hh);
-                xn[k][2 * hh]     = t.x;
-                xn[k][2 * hh + 1] = t.y;
+#pragma unroll
+                for (int hh = 0; hh < U / 2; ++hh)
+                {
+                    const double2 t = (L3K_DBG(a) & 2) ? make_double2(1e-9 * double(node), 1e-9)
+                                                  : *reinterpret_cast< const double2* >(p + 2 * hh);
+                    xn[k][2 * hh]     = t.x;
+                    xn[k][2 * hh + 1] = t.y;
+                }
+            }
+            else // an odd number of unknowns: a node's row is not 16-byte aligned -- 8-byte loads (adjacent lanes, adjacent nodes)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xn[k][u] = (L3K_DBG(a) & 2) ? 1e-9 * double(node) : p[u];
             }
             dm_nxt[k] = flagged ? dirichletBits< U >(a.dirichlet, node) : 0u;
 #pragma unroll
@@ -516,7 +556,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     in1[k] = u0[k][2 * g + 1];
                 }
                 sweepEO< N1, NQ, false, false >(in0, o0, tI);
-                sweepEO< N1, NQ, false, false >(in1, o1, tI);
+                sweepEOSecond< N1, NQ, false, false >(2 * g + 1 < NF, in1, o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufA, g, at(i1, j1, q), o0[q], o1[q]);
@@ -550,7 +590,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[NQ], o1[NQ];
                 sweepEO< N1, NQ, false, false >(in0[g - gb], o0, tI);
-                sweepEO< N1, NQ, false, false >(in1[g - gb], o1, tI);
+                sweepEOSecond< N1, NQ, false, false >(2 * g + 1 < NF, in1[g - gb], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(INPLACE ? bufA : bufB, g, at(iq, q, kq), o0[q], o1[q]);
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[NQ], o1[NQ];
                 sweepEO< N1, NQ, false, false >(in0[g - gb], o0, tI);
-                sweepEO< N1, NQ, false, false >(in1[g - gb], o1, tI);
+                sweepEOSecond< N1, NQ, false, false >(2 * g + 1 < NF, in1[g - gb], o1, tI);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
@@ -635,7 +675,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[NQ], o1[NQ];
                 sweepEO< NQ, NQ, true, false >(in0[g - gb], o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1[g - gb], o1, tC);
+                sweepEOSecond< NQ, NQ, true, false >(2 * g + 1 < DF, in1[g - gb], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
@@ -668,7 +708,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[NQ], o1[NQ];
                 sweepEO< NQ, NQ, true, false >(in0[g - gb], o0, tC);
-                sweepEO< NQ, NQ, true, false >(in1[g - gb], o1, tC);
+                sweepEOSecond< NQ, NQ, true, false >(2 * g + 1 < DF, in1[g - gb], o1, tC);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufA, g, at(qa, qb, q), o0[q], o1[q]);
@@ -790,7 +830,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[NQ], o1[NQ];
                 sweepEO< NQ, NQ, true, false >(e0[g], o0, tCt);
-                sweepEO< NQ, NQ, true, false >(e1[g], o1, tCt);
+                sweepEOSecond< NQ, NQ, true, false >(2 * g + 1 < U, e1[g], o1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufB, g, at(qa, q, qb), o0[q], o1[q]);
@@ -815,7 +855,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     b1[q] = t.y;
                 }
                 sweepEO< NQ, NQ, true, true >(z0, b0, tCt);
-                sweepEO< NQ, NQ, true, true >(z1, b1, tCt);
+                sweepEOSecond< NQ, NQ, true, true >(2 * g + 1 < U, z1, b1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     stg(bufB, g, at(qa, qb, q), b0[q], b1[q]);
@@ -842,7 +882,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     w1[q]  = v[q][2 * g + 1] + tb.y;
                 }
                 sweepEO< NQ, NQ, true, true >(r10, w0, tCt);
-                sweepEO< NQ, NQ, true, true >(r11, w1, tCt);
+                sweepEOSecond< NQ, NQ, true, true >(2 * g + 1 < U, r11, w1, tCt);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                 {
@@ -863,7 +903,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                     w1[q] = v[q][2 * g + 1];
                 }
                 sweepEO< NQ, N1, false, false >(w0, o0, tIt);
-                sweepEO< NQ, N1, false, false >(w1, o1, tIt);
+                sweepEOSecond< NQ, N1, false, false >(2 * g + 1 < U, w1, o1, tIt);
 #pragma unroll
                 for (int i = 0; i < N1; ++i)
                     stg(bufB, g, at(i, qa, qb), o0[i], o1[i]);
@@ -895,7 +935,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[N1], o1[N1];
                 sweepEO< NQ, N1, false, false >(in0[g - gb], o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1[g - gb], o1, tIt);
+                sweepEOSecond< NQ, N1, false, false >(2 * g + 1 < U, in1[g - gb], o1, tIt);
 #pragma unroll
                 for (int j = 0; j < N1; ++j)
                     stg(bufA, g, at(iq, j, kq), o0[j], o1[j]);
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             {
                 double o0[N1], o1[N1];
                 sweepEO< NQ, N1, false, false >(in0[g - gb], o0, tIt);
-                sweepEO< NQ, N1, false, false >(in1[g - gb], o1, tIt);
+                sweepEOSecond< NQ, N1, false, false >(2 * g + 1 < U, in1[g - gb], o1, tIt);
                 // scatterSumFact skips Dirichlet dofs (MatrixFreeSystem.hpp:517-536).  Here their staged values become 0 -- the
                 // scatter then ADDS 0 to those rows (or stores beta * y on exclusive ones), which leaves them as they are -- so
                 // that elements touching the Dirichlet boundary take the same unrolled scatter as all others (they used to loop
@@ -960,7 +1000,14 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 {
                     const uint32_t slot = (k & 1) ? sw[k >> 1] >> 16 : sw[k >> 1] & 0xffffu;
                     double*        dstl = sb + slot * U + 2 * g;
-                    *reinterpret_cast< double2* >(dstl) = ENERGY ? make_double2(a.alpha * o0[k], a.alpha * o1[k]) : make_double2(o0[k], o1[k]); // (U is even)
+                    if constexpr (U % 2 == 0)
+                        *reinterpret_cast< double2* >(dstl) = ENERGY ? make_double2(a.alpha * o0[k], a.alpha * o1[k]) : make_double2(o0[k], o1[k]);
+                    else // (an odd U: node rows of the staging buffer are 8-byte aligned only)
+                    {
+                        dstl[0] = ENERGY ? a.alpha * o0[k] : o0[k];
+                        if (2 * g + 1 < U)
+                            dstl[1] = ENERGY ? a.alpha * o1[k] : o1[k];
+                    }
                 }
                 if constexpr (ENERGY && ENERGY_AT_END)
                 {
@@ -976,8 +1023,17 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                         // the element's x values in registers across all stages -- 34 spilled registers)
                         const int64_t node = static_cast< uint32_t >(opaqueCopy(static_cast< int >(ids_cur[k])));
                         const double* px   = (!SPLIT || node < n_owned_nodes ? ax_e + node * U : axg_e + (node - n_owned_nodes) * U) + 2 * g;
-                        const double2 xv   = *reinterpret_cast< const double2* >(px);
-                        en_e += xv.x * o0[k] + xv.y * o1[k]; // (o0, o1 are 0 on Dirichlet dofs: zeroed above)
+                        if constexpr (U % 2 == 0)
+                        {
+                            const double2 xv = *reinterpret_cast< const double2* >(px);
+                            en_e += xv.x * o0[k] + xv.y * o1[k]; // (o0, o1 are 0 on Dirichlet dofs: zeroed above)
+                        }
+                        else
+                        {
+                            en_e += px[0] * o0[k];
+                            if (2 * g + 1 < U)
+                                en_e += px[1] * o1[k];
+                        }
                     }
                 }
             }
@@ -1030,11 +1086,15 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
             // (SG is a multiple of U: a lane keeps its unknown and moves SG / U slots per round -- every LDS address below is
             // one per-lane base plus a compile-time offset)
             static_assert(SG % U == 0);
-            const int             sl_node = sl / U, sl_o = sl % U, sl_node2 = sl / (U / 2), sl_o2 = 2 * (sl % (U / 2));
+            // exclusive (element-internal) nodes: 16-byte stores, two unknowns per lane -- or, with an odd number of unknowns
+            // (8-byte aligned rows), one unknown per lane like the shell slots: XW doubles per lane, UX = U / XW lanes per node
+            constexpr int         XW = U % 2 == 0 ? 2 : 1, UX = U / XW;
+            using xval_t = std::conditional_t< XW == 2, double2, double >;
+            const int             sl_node = sl / U, sl_o = sl % U, sl_node2 = sl / UX, sl_o2 = XW * (sl % UX);
             const uint32_t* const ids1 = idsS + sl_node;
             const double* const   sb1  = sb + sl;
             const uint32_t* const ids2 = idsS + sl_node2;
-            const double2* const  sb2  = reinterpret_cast< const double2* >(sb) + sl;
+            const xval_t* const   sb2  = reinterpret_cast< const xval_t* >(sb) + sl;
             // FLAGGED: the element touches a Dirichlet dof (those dofs are skipped / written as beta*y, :517-536).  Only the
             // common variant (exclusive range present, no Dirichlet dof) is unrolled: without branches inside the rounds
             // its LDS reads are issued ahead of the address arithmetic of earlier rounds
@@ -1058,34 +1118,53 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 else
                     unsafeAtomicAdd(dst, val);
             };
+            // out = val + beta * old on an exclusive row (the pre-scaling pass skipped it), for both widths
+            auto exclStore = [&](double* dst, xval_t out) {
+                if constexpr (XW == 2)
+                {
+                    if (a.beta != 0.)
+                    {
+                        const double2 old = *reinterpret_cast< const double2* >(dst);
+                        out.x += a.beta * old.x;
+                        out.y += a.beta * old.y;
+                    }
+                    *reinterpret_cast< double2* >(dst) = out;
+                }
+                else
+                    *dst = a.beta != 0. ? out + a.beta * *dst : out;
+            };
             auto exclRound = [&]< int NSH_, bool FLAGGED >(int r) {
-                if (NSH_ * (U / 2) + r * SG + sl >= NN * (U / 2))
+                if (NSH_ * UX + r * SG + sl >= NN * UX)
                     return;
-                const int64_t node = ids2[NSH_ + r * (SG / (U / 2))];
+                const int64_t node = ids2[NSH_ + r * (SG / UX)];
                 const int64_t dof  = node * U + sl_o2;
-                const double2 val  = sb2[NSH_ * (U / 2) + r * SG];
+                const xval_t  val  = sb2[NSH_ * UX + r * SG];
                 double*       dst  = ay + dof; // (exclusive nodes are owned)
-                double2       out  = val;
+                xval_t        out  = val;
                 if constexpr (FLAGGED)
                 {
-                    out.x = a.dirichlet[dof] != 0 ? 0. : val.x;
-                    out.y = a.dirichlet[dof + 1] != 0 ? 0. : val.y;
+                    if constexpr (XW == 2)
+                    {
+                        out.x = a.dirichlet[dof] != 0 ? 0. : val.x;
+                        out.y = a.dirichlet[dof + 1] != 0 ? 0. : val.y;
+                    }
+                    else
+                        out = a.dirichlet[dof] != 0 ? 0. : val;
                 }
                 if (L3K_DBG(a) & 1)
                 {
-                    if (val.x == 1.2345e300)
-                        *dst = val.x;
+                    double first;
+                    if constexpr (XW == 2)
+                        first = val.x;
+                    else
+                        first = val;
+                    if (first == 1.2345e300)
+                        *dst = first;
                     return;
                 }
-                if (a.beta != 0.)
-                {
-                    const double2 old = *reinterpret_cast< const double2* >(dst);
-                    out.x += a.beta * old.x;
-                    out.y += a.beta * old.y;
-                }
-                *reinterpret_cast< double2* >(dst) = out;
+                exclStore(dst, out);
             };
-            constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * (U / 2) + SG - 1) / SG;
+            constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * UX + SG - 1) / SG;
             if (a.fuse_beta && !flagged)
             {
 #ifdef L3K_ABLATION
@@ -1100,10 +1179,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 // round trip instead of one per round -- the registers of the sweeps are free here), then the address
                 // arithmetic and the memory instructions back to back.  Full rounds are unconditional; only the last round
                 // of each kind has lanes beyond the end
-                constexpr int  NSHU = Cfg::NSH * U, NXH = (NN - Cfg::NSH) * (U / 2);
+                constexpr int  NSHU = Cfg::NSH * U, NXH = (NN - Cfg::NSH) * UX;
                 uint32_t       nid[RS], nid2[RX > 0 ? RX : 1]; // (order 1 has no exclusive slots)
                 double         val[RS];
-                double2        val2[RX > 0 ? RX : 1];
+                xval_t         val2[RX > 0 ? RX : 1];
                 constexpr bool part1 = RS * SG > NSHU, part2 = RX * SG > NXH;
                 const bool     in1 = !part1 || (RS - 1) * SG + sl < NSHU, in2 = !part2 || (RX - 1) * SG + sl < NXH;
 #pragma unroll
@@ -1116,8 +1195,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 for (int r = 0; r < RX; ++r)
                     if (r + 1 < RX || in2)
                     {
-                        nid2[r] = ids2[Cfg::NSH + r * (SG / (U / 2))];
-                        val2[r] = sb2[Cfg::NSH * (U / 2) + r * SG];
+                        nid2[r] = ids2[Cfg::NSH + r * (SG / UX)];
+                        val2[r] = sb2[Cfg::NSH * UX + r * SG];
                     }
 #pragma unroll
                 for (int r = 0; r < RS; ++r)
@@ -1132,15 +1211,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::min_waves)) void sumfactF
                 for (int r = 0; r < RX; ++r)
                     if (r + 1 < RX || in2)
                     {
-                        double* dst = ay + int64_t(nid2[r]) * U + sl_o2; // (exclusive nodes are owned)
-                        double2 out = val2[r];
-                        if (a.beta != 0.)
-                        {
-                            const double2 old = *reinterpret_cast< const double2* >(dst);
-                            out.x += a.beta * old.x;
-                            out.y += a.beta * old.y;
-                        }
-                        *reinterpret_cast< double2* >(dst) = out;
+                        exclStore(ay + int64_t(nid2[r]) * U + sl_o2, val2[r]); // (exclusive nodes are owned)
                     }
 #endif
             }
@@ -1269,7 +1340,7 @@ int planSumfactFast(const ElemArgs& a, FastRoute& r)
             pd.n_cus = prop.multiProcessorCount;
             // resident single-wave workgroups per CU: limited by LDS (160 KiB) and by the VGPR budget (min_waves per SIMD)
             const int by_lds = int((160 * 1024) / Cfg::lds);
-            pd.waves_cu      = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::min_waves ? 4 * Cfg::min_waves : by_lds);
+            pd.waves_cu      = by_lds < 1 ? 1 : (by_lds > 4 * Cfg::wavesPerSimd(MULTI) ? 4 * Cfg::wavesPerSimd(MULTI) : by_lds);
             pd.ready         = true;
         }
         r.n_cus = pd.n_cus, r.waves_cu = pd.waves_cu;

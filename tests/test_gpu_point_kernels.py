@@ -112,6 +112,8 @@ def test_mesh_apply_diag_rhs_at_two_times(ctx, kid, ne, p, vo, route):
     gd = np.random.default_rng(6).uniform(-1, 1, (1, part.n_local_nodes * U)) * mask[None, :]
     results = []
     with ctx.tuning(generic_below=ROUTES[route]):
+        # the route under test -- kernels with an odd number of unknowns (U = 1, 3) take the one-wave-per-element kernel too
+        assert mf.route().startswith(f"sumfactFastKernel<p={p},nq={nq},U={U},F={F}>" if route == "fast" else "sumfactApplyKernel"), mf.route()
         for t in (0.0, 0.85):
             mf.set_time(t)
             X, Y = dev(x), dev(y0)
