@@ -177,6 +177,23 @@ extern "C" int l3k_debug_stamps(long long* host, int n)
 namespace
 {
 
+// ElemArgs::scratch_alloc: the context's scratch arena, at least `bytes` large (kernels in flight on the context's stream may
+// still use the old arena when it has to grow: hipFree waits for them)
+double* contextScratch(void* owner, size_t bytes)
+{
+    auto* ctx = static_cast< l3k_ctx* >(owner);
+    if (bytes <= ctx->scratch_bytes)
+        return ctx->scratch;
+    if (ctx->scratch)
+        (void)hipFree(ctx->scratch);
+    ctx->scratch       = nullptr;
+    ctx->scratch_bytes = 0;
+    if (hipMalloc(reinterpret_cast< void** >(&ctx->scratch), bytes) != hipSuccess)
+        return nullptr;
+    ctx->scratch_bytes = bytes;
+    return ctx->scratch;
+}
+
 int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
 {
     const l3k_mesh* m = mf->mesh;
@@ -190,6 +207,8 @@ int fillArgs(l3k_mf* mf, int which, int ncols, l3k::dev::ElemArgs& a)
     a.slot_tab             = m->slot_tab.ptr;
     a.all_affine           = m->all_affine ? 1 : 0;
     a.tune                 = &mf->ctx->tune;
+    a.scratch_alloc        = &contextScratch;
+    a.scratch_owner        = mf->ctx;
     // dynamic batch distribution of the single-wave kernel (l3k_tuning::static_deal: the static deal)
     a.work_counters        = mf->ctx->tune.static_deal ? nullptr : mf->ctx->work_counters;
     a.energy        = ncols == 1 ? mf->energy_target : nullptr;

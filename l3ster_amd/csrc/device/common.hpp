@@ -95,6 +95,13 @@ struct ElemArgs
     int     all_affine; // every element of the mesh is a parallelepiped (one Jacobian per element)
     int     n_cols;     // single-wave kernel, multi-column variant: columns applied per element pass (0 / 1: one)
     const l3k_tuning* tune; // HOST: the context's launch-route settings (read by the launchers; nullptr: defaults)
+    // Shapes whose per-element buffers exceed the 160 KiB of LDS (e.g. the reference's NS3D benchmark kernel at order 4: 14 fields x
+    // 8^3 points x 5 buffers = 286 KB) run the same kernels on a per-workgroup working set in GLOBAL memory: `scratch` is the device
+    // arena (workgroup b uses [b * bytes, (b + 1) * bytes)), obtained by the launcher from the HOST callback (the context owns and
+    // grows it)
+    double* scratch;
+    double* (*scratch_alloc)(void* owner, size_t bytes);
+    void*   scratch_owner;
     int     ref_z0;     // applies pass z = 0 to the domain kernel (the reference's evalAtHexQPs, SumFactorization.hpp:732) instead of the true z
     int     dense; // dofs_per_node == n_unknowns and field_inds = identity: a node's unknowns are one contiguous vector
     int     dbg; // ablation switches for tools/kbench.py (env L3K_DEBUG_FLAGS): read only by L3K_ABLATION builds
@@ -173,5 +180,7 @@ template < typename K >
 struct ResidualId;
 
 void setError(const char* fmt, ...);
+// compute units of the current device (cached per device)
+int deviceComputeUnits();
 } // namespace l3k::dev
 #endif

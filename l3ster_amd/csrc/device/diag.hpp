@@ -19,7 +19,8 @@ constexpr size_t diagLdsBytes()
     return sizeof(double) * (size_t(4 * K::params.n_unknowns + 5 * K::params.n_fields) * M * M * M + 24);
 }
 
-template < typename K, int P, int NQ >
+// GS: working set in the workgroup's slice of a.scratch instead of the LDS, persistent workgroups (sumfact_apply.hpp)
+template < typename K, int P, int NQ, bool GS = false >
 __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const ElemArgs a, const K kern)
 {
     constexpr KernelParams params = K::params;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const El
     using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, 1} >;
 
     extern __shared__ double lds[];
-    double* const            Gb  = lds;              // [U][M3] coefficient array of the current (k,l)
+    double* const            Gb  = GS ? a.scratch + size_t(blockIdx.x) * (diagLdsBytes< K, P, NQ >() / sizeof(double)) : lds; // [U][M3] coefficient array of the current (k,l)
     double* const            T1  = Gb + U * M3;      // sweep temporaries
     double* const            T2  = T1 + U * M3;
     double* const            acc = T2 + U * M3;      // [U][M3] element diagonal at the nodes
@@ -38,9 +39,12 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const El
     double* const            vs  = Fv + 5 * F * M3;  // [8][3]
 
     const int       tid = threadIdx.x;
-    const int64_t   e   = a.elem_begin + blockIdx.x;
-    const uint32_t* en  = a.elem_nodes + e * NN;
     const double*   tab[3] = {a.tables + TL.offII(), a.tables + TL.offID(), a.tables + TL.offDD()};
+    int64_t         eb = blockIdx.x;
+    do
+    {
+    const int64_t   e   = a.elem_begin + eb;
+    const uint32_t* en  = a.elem_nodes + e * NN;
 
     if (tid < 24)
         vs[tid] = a.elem_verts[e * 24 + tid];
@@ -141,6 +145,9 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const El
         double*       dst = dof < a.n_owned_dofs ? a.diag + dof : a.diag_g + (dof - a.n_owned_dofs);
         unsafeAtomicAdd(dst, acc[u * M3 + i]);
     }
+    if constexpr (GS)
+        __syncthreads();
+    } while (GS && (eb += gridDim.x) < a.elem_count);
 }
 
 // diag + rhs of one element range: the rhs part runs the sum-factorised apply in RHS mode (B^T W (f - B g_D))
@@ -157,7 +164,28 @@ int launchDiagRhs(const ElemArgs& a, const void* kparam_blob, hipStream_t stream
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
     constexpr size_t lds = diagLdsBytes< K, P, NQ >();
-    static_assert(lds <= lds_limit_bytes, "diagonal kernel working set exceeds 160 KiB of LDS");
+    if constexpr (lds > lds_limit_bytes)
+    {
+        const int64_t  max_wgs = 2 * int64_t(deviceComputeUnits());
+        const unsigned grid    = static_cast< unsigned >(a.elem_count < max_wgs ? a.elem_count : max_wgs);
+        ElemArgs       ag      = a;
+        ag.scratch             = a.scratch_alloc ? a.scratch_alloc(a.scratch_owner, lds * grid) : nullptr;
+        if (!ag.scratch)
+        {
+            setError("could not obtain %zu bytes of global scratch for the diagonal kernel", lds * grid);
+            return -3;
+        }
+        hipLaunchKernelGGL((diagKernel< K, P, NQ, true >), dim3(grid), dim3(applyThreads< P, NQ >()), 0, stream, ag, kern);
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess)
+        {
+            setError("diagKernel (global scratch) launch failed: %s", hipGetErrorString(err));
+            return -3;
+        }
+        return 0;
+    }
+    else
+    {
     auto        kernel   = diagKernel< K, P, NQ >;
     static bool attr_set = false;
     if (!attr_set)
@@ -178,6 +206,7 @@ int launchDiagRhs(const ElemArgs& a, const void* kparam_blob, hipStream_t stream
         return -3;
     }
     return 0;
+    }
 }
 } // namespace l3k::dev
 #endif

@@ -273,7 +273,10 @@ constexpr size_t applyLdsBytes()
 // RHS_MODE == true : rhs += B^T W (f - B g)   with g = Dirichlet values on Dirichlet dofs, 0 elsewhere
 //                    (precomputeDiagRhsImpl's rhs, algsys/EvaluateLocalOperator.hpp:187,195-207, in sum-factorised
 //                    form; nothing is skipped in the scatter, as scatterInit :377-390)
-template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT = R, int C0 = 0 >
+// GS (global scratch): the five buffers do not fit the LDS -- the workgroup keeps them in its slice of a.scratch (global memory,
+// served by the L2 / MALL) and walks the elements persistently.  Same code otherwise: __syncthreads() orders a workgroup's global
+// accesses too (its waves share one CU and its L1).
+template < typename K, int P, int NQ, int R, bool RHS_MODE, int RT = R, int C0 = 0, bool GS = false >
 __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(const ElemArgs a, const K kern)
 {
     constexpr KernelParams params = K::params;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     constexpr TableLayout  TL{N1, NQ};
 
     extern __shared__ double lds[];
-    double* const            B0 = lds;
+    double* const            B0 = GS ? a.scratch + size_t(blockIdx.x) * (applyLdsBytes< K, P, NQ, R >() / sizeof(double)) : lds;
     double* const            B1 = B0 + NF * M3;
     double* const            B2 = B1 + NF * M3;
     double* const            B3 = B2 + NF * M3;
@@ -291,10 +294,13 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
     double* const            vs = B4 + NF * M3; // [8][3]
 
     const int            tid  = threadIdx.x;
-    const int64_t        e    = a.elem_begin + blockIdx.x;
-    const uint32_t*      en   = a.elem_nodes + e * NN;
     const double* const  tabI = a.tables + TL.offI();
     const double* const  tabC = a.tables + TL.offC();
+    int64_t              eb   = blockIdx.x; // position in the launch's element range (GS: persistent workgroups)
+    do
+    {
+    const int64_t        e    = a.elem_begin + eb;
+    const uint32_t*      en   = a.elem_nodes + e * NN;
 
     if (tid < 24)
         vs[tid] = a.elem_verts[e * 24 + tid];
@@ -428,6 +434,9 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void sumfactApplyKernel(
             }
         }
     }
+    if constexpr (GS)
+        __syncthreads(); // (the buffers are rewritten by the next element)
+    } while (GS && (eb += gridDim.x) < a.elem_count);
 }
 
 inline constexpr size_t lds_limit_bytes = 160 * 1024; // LDS per CU on gfx950; one workgroup may use all of it
@@ -436,11 +445,13 @@ inline constexpr size_t lds_limit_bytes = 160 * 1024; // LDS per CU on gfx950; o
 template < typename K, int P, int NQ, int R >
 int describeSumfactApply(const ElemArgs& a, char* buf, size_t n)
 {
-    constexpr bool by_columns = applyLdsBytes< K, P, NQ, R >() > lds_limit_bytes && R > 1;
-    std::snprintf(buf, n, "sumfactApplyKernel<p=%d,nq=%d,U=%d,F=%d,R=%d>: generic LDS kernel, one element per %d-thread workgroup, %zu B LDS%s%s",
-                  P, NQ, K::params.n_unknowns, K::params.n_fields, by_columns ? 1 : R, applyThreads< P, NQ >(),
-                  applyLdsBytes< K, P, NQ, by_columns ? 1 : R >(), by_columns ? ", column by column (the R-column working set exceeds the LDS)" : "",
-                  a.dense ? "" : ", non-dense dof layout");
+    constexpr bool   by_columns = applyLdsBytes< K, P, NQ, R >() > lds_limit_bytes && R > 1;
+    constexpr size_t ws         = applyLdsBytes< K, P, NQ, by_columns ? 1 : R >();
+    std::snprintf(buf, n, "sumfactApplyKernel<p=%d,nq=%d,U=%d,F=%d,R=%d>: generic kernel, %s, %zu B %s%s%s",
+                  P, NQ, K::params.n_unknowns, K::params.n_fields, by_columns ? 1 : R,
+                  ws > lds_limit_bytes ? "persistent workgroups on GLOBAL scratch (the element's buffers exceed the LDS)" : "one element per workgroup",
+                  ws, ws > lds_limit_bytes ? "of global scratch per workgroup" : "LDS",
+                  by_columns ? ", column by column (the R-column working set exceeds the LDS)" : "", a.dense ? "" : ", non-dense dof layout");
     return 0;
 }
 
@@ -479,9 +490,39 @@ int launchSumfactApply(const ElemArgs& a, const void* kparam_blob, hipStream_t s
         // kernel still sees an E x R rhs and column c of it is used
         return launchColumns< K, P, NQ, RHS_MODE, R, 0 >(a, kparam_blob, stream);
     }
+    else if constexpr (applyLdsBytes< K, P, NQ, R >() > lds_limit_bytes)
+    {
+        // one column and still too large for the LDS: the global-scratch variant, persistent workgroups (two per CU: no LDS, the
+        // registers admit them), each on its own slice of the context's scratch arena
+        K kern{};
+        if (kparam_blob)
+            __builtin_memcpy(&kern, kparam_blob, sizeof(K));
+        constexpr size_t ws = applyLdsBytes< K, P, NQ, R >();
+        const int64_t    max_wgs = 2 * int64_t(deviceComputeUnits());
+        const unsigned   grid = static_cast< unsigned >(a.elem_count < max_wgs ? a.elem_count : max_wgs);
+        if (!a.scratch_alloc)
+        {
+            setError("this shape needs %zu bytes per element in global scratch (its buffers exceed the LDS) and the caller gave no arena", ws);
+            return -3;
+        }
+        ElemArgs ag = a;
+        ag.scratch  = a.scratch_alloc(a.scratch_owner, ws * grid);
+        if (!ag.scratch)
+        {
+            setError("could not allocate %zu bytes of global scratch for the element kernel", ws * grid);
+            return -3;
+        }
+        hipLaunchKernelGGL((sumfactApplyKernel< K, P, NQ, R, RHS_MODE, RT, C0, true >), dim3(grid), dim3(applyThreads< P, NQ >()), 0, stream, ag, kern);
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess)
+        {
+            setError("sumfactApplyKernel (global scratch) launch failed: %s", hipGetErrorString(err));
+            return -3;
+        }
+        return 0;
+    }
     else
     {
-        static_assert(applyLdsBytes< K, P, NQ, R >() <= lds_limit_bytes, "element working set exceeds 160 KiB of LDS");
         K kern{};
         if (kparam_blob)
             __builtin_memcpy(&kern, kparam_blob, sizeof(K));

@@ -2,6 +2,7 @@
 #include "../device/common.hpp"
 
 #include <cstdarg>
+#include <mutex>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -36,6 +37,21 @@ std::vector< PluginKernel >& pluginKernels()
     return t;
 }
 } // namespace
+int deviceComputeUnits()
+{
+    static int        cus[64] = {};
+    static std::mutex m;
+    int               dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    std::lock_guard< std::mutex > lock{m};
+    if (cus[dev] == 0)
+    {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
 const l3k_tuning& defaultTuning()
 {
     static const l3k_tuning t{.generic_below = 1500, .static_deal = 0, .waves_per_cu = 0, .no_affine = 0, .column_by_column = 0,

@@ -117,12 +117,17 @@ struct l3k_ctx
     uint32_t*   work_counters = nullptr; // batch counters of the single-wave element kernel (8 x 128 bytes) + one more line:
     // the counter of l3k_assembled_scatter's entries outside the graph (no allocation per call)
     unsigned long long* missCounter() const { return reinterpret_cast< unsigned long long* >(work_counters + 8 * 32); }
+    // global-memory working sets of the element kernels whose buffers exceed the LDS (ElemArgs::scratch): grown on demand
+    double* scratch       = nullptr;
+    size_t  scratch_bytes = 0;
     ~l3k_ctx()
     {
         if (red_ws)
             (void)hipFree(red_ws);
         if (work_counters)
             (void)hipFree(work_counters);
+        if (scratch)
+            (void)hipFree(scratch);
     }
 };
 struct l3k_mesh
