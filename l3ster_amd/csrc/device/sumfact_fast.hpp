@@ -1101,6 +1101,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
             auto shellRound = [&]< int NSH_, bool FLAGGED >(int r) {
                 if ((r + 1) * SG > NSH_ * U && r * SG + sl >= NSH_ * U)
                     return;
+                // ablation 128: every other shell round dropped -- half the atomic adds (and their LDS reads and address arithmetic):
+                // a generous upper bound for what summing shared faces of an element block in LDS could save (wrong results)
+                if ((L3K_DBG(a) & 128) && (r & 1))
+                    return;
                 const int64_t node = ids1[r * (SG / U)];
                 const int64_t dof  = node * U + sl_o;
                 const double  val  = sb1[r * SG];

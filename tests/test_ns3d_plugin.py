@@ -24,14 +24,14 @@ SOURCE = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernels"
 @pytest.fixture(scope="module")
 def ns3d():
     from l3ster_amd import plugin
-    return plugin.compile_kernel("NS3D", SOURCE, KID, shapes=[(2, 4, 1), (4, 8, 1)])
+    return plugin.compile_kernel("NS3D", SOURCE, KID, shapes=[(2, 4, 1), (4, 8, 1), (6, 12, 1)])
 
 
 def test_plugin_builds_and_registers(ns3d):
     from l3ster_amd import system
     info = system.kernel_info(ns3d)
     assert (info["n_equations"], info["n_unknowns"], info["n_fields"], info["param_bytes"]) == (8, 7, 7, 0)
-    assert (KID, 2, 4, 1) in system.instances() and (KID, 4, 8, 1) in system.instances()
+    assert all((KID, p, 2 * p, 1) in system.instances() for p in (2, 4, 6))
     assert O.kernel_params(O.KERNEL_NS3D) == dict(dim=3, E=8, U=7, F=7)
 
 
@@ -80,15 +80,16 @@ def test_single_element_vs_golden(ns3d, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("p", [2, 4])
+@pytest.mark.parametrize("p", [2, 4, 6])
 def test_mesh_vs_oracle(ns3d, p):
-    """apply (alpha, beta; Dirichlet on the three velocity components of all sides), diag and lifted rhs on a perturbed 2^3 mesh, and
-    K_e / F_e of two of its elements entry by entry, against the oracle."""
+    """apply (alpha, beta; Dirichlet on the three velocity components of all sides), diag and lifted rhs on a perturbed 2^3 mesh
+    (2 x 1 x 1 at p = 6), and K_e / F_e of two of its elements entry by entry, against the oracle (p = 6: F_e and the checksum
+    only -- the oracle's dense 2401 x 2401 K_e costs 80 GFLOP per element on the CPU)."""
     import torch
     from l3ster_amd import system
     ctx = _ctx()
     U, F, nq = 7, 7, 2 * p
-    part = system.CubePartition(2, p, perturb=0.15)
+    part = system.CubePartition(2 if p < 6 else (2, 1, 1), p, perturb=0.15)
     mask = part.dirichlet_mask(U, unknowns=(0, 1, 2))
     fields = np.random.default_rng(4).uniform(-1, 1, (F, part.n_local_nodes))
     assert system.n_qps1d(p, *OPTS[:2]) == nq
@@ -104,8 +105,8 @@ def test_mesh_vs_oracle(ns3d, p):
     for route, below in routes:
         with ctx.tuning(generic_below=below):
             line = mf.route()
-            if p == 4:  # 286 KB of buffers per element: the global-scratch variant of the generic kernel
-                assert "GLOBAL scratch" in line and "sumfactApplyKernel<p=4,nq=8,U=7,F=7" in line, line
+            if p >= 4:  # 286 KB (p = 4) / 968 KB (p = 6) of buffers per element: the global-scratch variant of the generic kernel
+                assert "GLOBAL scratch" in line and f"sumfactApplyKernel<p={p},nq={2 * p},U=7,F=7" in line, line
             X, Y = _dev(x), _dev(y0)
             mf.apply(X, Y, 1.5, -0.25)
             assert rel_err(Y.cpu().numpy().T, y_ref) < 1e-11, line
@@ -114,8 +115,16 @@ def test_mesh_vs_oracle(ns3d, p):
     K, Fe, cs = mf.local_assemble(0, 2, want_checksum=True)
     _, _, cs_stream = mf.local_assemble(0, 2, want_K=False, want_F=False, want_checksum=True)
     K, Fe = K.cpu().numpy(), Fe.cpu().numpy()
+    np.testing.assert_allclose(cs_stream.cpu().numpy(), cs.cpu().numpy(), rtol=1e-11)
+    if p == 6:  # F_e through the oracle's lifted-rhs function without Dirichlet dofs; K_e through its action on a vector
+        for e in range(2):
+            nf = fields[:, part.elem_nodes[e]].T
+            _, F_ref = O.diag_rhs_local(O.KERNEL_NS3D, p, nq, 1, part.elem_verts[e], None, None, nf)
+            assert np.abs(Fe[e].T - F_ref).max() < 1e-12 * max(1.0, np.abs(F_ref).max()), e
+            v = np.random.default_rng(e).uniform(-1, 1, (K.shape[1], 1))
+            assert rel_err(K[e] @ v, O.apply_local(O.KERNEL_NS3D, p, nq, part.elem_verts[e], v, nf)) < 1e-12, e
+        return
     for e in range(2):
         K_ref, F_ref = O.assemble_local(O.KERNEL_NS3D, p, nq, 1, part.elem_verts[e], fields[:, part.elem_nodes[e]].T)
         assert np.abs(K[e] - K_ref).max() < 1e-12 * np.abs(K_ref).max(), e
         assert np.abs(Fe[e].T - F_ref).max() < 1e-12 * max(1.0, np.abs(F_ref).max()), e
-    np.testing.assert_allclose(cs_stream.cpu().numpy(), cs.cpu().numpy(), rtol=1e-11)

@@ -1,6 +1,6 @@
 """Kernel micro-benchmark: times the element kernel alone (HIP events on the launch stream) for one shape, with the
 ablation switches of L3K_DEBUG_FLAGS (1 no scatter, 2 no gather loads, 4 no QP stage, 8 no sweeps, 16 plain stores
-instead of atomics).  Usage: python tools/kbench.py --order 6 --ne 32 [--flags 0,1,2,...]"""
+instead of atomics, 128 every other shell round of the scatter dropped: half the atomics).  Usage: python tools/kbench.py --order 6 --ne 32 [--flags 0,1,2,...]"""
 import argparse
 import os
 import subprocess

@@ -39,13 +39,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     a = ap.parse_args()
     src = open(os.path.join(ROOT, "tests", "kernels", "ns3d.hpp")).read()
-    plugin.compile_kernel("NS3D", src, KID, shapes=[(2, 4, 1), (4, 8, 1)])
+    plugin.compile_kernel("NS3D", src, KID, shapes=[(2, 4, 1), (4, 8, 1), (6, 12, 1)])
     torch.cuda.set_device(0)
     ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
     ctx.set_tuning(generic_below=0)
-    for p in (2, 4):
+    for p in (2, 4, 6):
         nq, n_nodes = 2 * p, (p + 1) ** 3
-        part = system.CubePartition(a.ne, p, perturb=0.1)
+        part = system.CubePartition(a.ne if p < 6 else min(a.ne, 10), p, perturb=0.1)
         mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, part.dirichlet_mask(U, unknowns=(0, 1, 2))), KID, asm_opts=(1, 1, 0))
         mf.set_fields(system.synthetic_vector_torch(part.node_grid_id, F, "cuda", seed=7).view(-1, F).t().contiguous())
         X = system.synthetic_vector_torch(part.node_grid_id, U, "cuda")
@@ -63,7 +63,7 @@ def main():
             with ctx.tuning(generic_below=10 ** 9):
                 out["apply_generic_route"] = mf.route()
                 out["apply_generic_ms"] = median_ms(lambda: mf.apply_elems(2, X, None, Y, None, 1.0, 0.0), a.steps)
-        batch = min(part.n_elems, 4096 if p == 2 else 512)
+        batch = min(part.n_elems, {2: 4096, 4: 512, 6: 128}[p])
         ms = median_ms(lambda: mf.local_assemble(0, batch, want_K=False, want_F=False, want_checksum=True), a.steps)
         out.update(assembly_batch=batch, assembly_ms_per_batch=ms, assembly_matrices_per_s=batch / (ms * 1e-3),
                    assembly_reference_model_tflops=batch * n_qp * asm_flops_qp / (ms * 1e-3) / 1e12,
