@@ -11,6 +11,8 @@
 // that also runs torch.distributed shares torch's copy (same SONAME).
 #include "objects.hpp"
 
+#include <algorithm>
+
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -194,16 +196,24 @@ int postImport(l3k_halo* h, int ncols, double* ghost, size_t ldg, hipEvent_t aft
     const auto& tp = h->tp;
     if (int rc = tp.group_begin(tp.user))
         return rc;
+    // (a failed send / recv must not leave the transport's group open -- an open RCCL group swallows every later call: the group
+    // is closed first, the FIRST error is what the caller sees)
+    int posted = 0;
     for (const auto& nb : h->nbrs)
-        for (int c = 0; c < ncols; ++c)
+        for (int c = 0; c < ncols && posted == 0; ++c)
         {
             if (nb.n_send > 0) // block of neighbour nb: [ncols][n_send]
-                if (int rc = tp.send(tp.user, h->sendbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), nb.rank, h->comm_stream))
-                    return rc;
-            if (nb.g1 > nb.g0)
-                if (int rc = tp.recv(tp.user, ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), nb.rank, h->comm_stream))
-                    return rc;
+                posted = tp.send(tp.user, h->sendbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), nb.rank, h->comm_stream);
+            if (posted == 0 && nb.g1 > nb.g0)
+                posted = tp.recv(tp.user, ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), nb.rank, h->comm_stream);
         }
+    if (posted != 0)
+    {
+        const std::string first = l3k::dev::lastError();
+        (void)tp.group_end(tp.user, h->comm_stream);
+        setError("%s", first.c_str());
+        return posted;
+    }
     if (int rc = tp.group_end(tp.user, h->comm_stream))
         return rc;
     L3K_HIP(hipEventRecord(done, h->comm_stream));
@@ -218,16 +228,22 @@ int postExport(l3k_halo* h, int ncols, const double* ghost, size_t ldg, hipEvent
     const auto& tp = h->tp;
     if (int rc = tp.group_begin(tp.user))
         return rc;
+    int posted = 0; // (as in postImport: the group is closed before an error is reported)
     for (const auto& nb : h->nbrs)
-        for (int c = 0; c < ncols; ++c)
+        for (int c = 0; c < ncols && posted == 0; ++c)
         {
             if (nb.g1 > nb.g0)
-                if (int rc = tp.send(tp.user, ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), nb.rank, h->comm_stream))
-                    return rc;
-            if (nb.n_send > 0)
-                if (int rc = tp.recv(tp.user, h->recvbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), nb.rank, h->comm_stream))
-                    return rc;
+                posted = tp.send(tp.user, ghost + ldg * c + nb.g0, size_t(nb.g1 - nb.g0), nb.rank, h->comm_stream);
+            if (posted == 0 && nb.n_send > 0)
+                posted = tp.recv(tp.user, h->recvbuf.ptr + nb.send_off * ncols + nb.n_send * c, size_t(nb.n_send), nb.rank, h->comm_stream);
         }
+    if (posted != 0)
+    {
+        const std::string first = l3k::dev::lastError();
+        (void)tp.group_end(tp.user, h->comm_stream);
+        setError("%s", first.c_str());
+        return posted;
+    }
     if (int rc = tp.group_end(tp.user, h->comm_stream))
         return rc;
     L3K_HIP(hipEventRecord(done, h->comm_stream));
@@ -343,6 +359,7 @@ struct InprocMsg
     hipEvent_t    ready; // recorded by the sender: the payload is complete
     hipEvent_t    done  = nullptr; // recorded by the receiver behind its copy
     bool          acked = false;
+    bool          failed = false; // the receiver rejected the message, or the sender's group was abandoned: no `done` event
 };
 } // namespace
 struct l3k_inproc_group
@@ -420,7 +437,34 @@ struct l3k_inproc_group
         static_cast< Endpoint* >(u)->recvs.push_back({buf, n, peer}); // matched at the end of the group
         return 0;
     }
+    // a group that failed: this endpoint's messages still queued are withdrawn (a later group would pair them with the wrong
+    // receive) and marked, so that nobody waits for them; its own receive list is dropped
+    static void abandon(Endpoint* ep)
+    {
+        l3k_inproc_group* g = ep->g;
+        {
+            std::lock_guard lock{g->m};
+            for (const auto& msg : ep->sends)
+            {
+                for (auto& [key, q] : g->channel)
+                    if (key.first == ep->rank)
+                        q.erase(std::remove(q.begin(), q.end(), msg), q.end());
+                if (!msg->acked)
+                    msg->acked = msg->failed = true;
+            }
+        }
+        g->cv.notify_all();
+        ep->sends.clear();
+        ep->recvs.clear();
+    }
     static int groupEnd(void* u, void* stream_)
+    {
+        const int rc = groupEndImpl(u, stream_);
+        if (rc != 0)
+            abandon(static_cast< Endpoint* >(u));
+        return rc;
+    }
+    static int groupEndImpl(void* u, void* stream_)
     {
         auto*             ep     = static_cast< Endpoint* >(u);
         l3k_inproc_group* g      = ep->g;
@@ -441,6 +485,11 @@ struct l3k_inproc_group
             }
             if (msg->n != r.n)
             {
+                {
+                    std::lock_guard lock{g->m}; // (the sender must not wait for a copy that will not happen)
+                    msg->acked = msg->failed = true;
+                }
+                g->cv.notify_all();
                 setError("in-process transport: rank %d expects %zu doubles from rank %d, which sent %zu", ep->rank, r.n, r.peer, msg->n);
                 return -1;
             }
@@ -466,6 +515,11 @@ struct l3k_inproc_group
                 {
                     setError("in-process transport: rank %d waited %d s for a receiver", ep->rank, int(timeout.count()));
                     return -3;
+                }
+                if (msg->failed)
+                {
+                    setError("in-process transport: a message of rank %d was rejected by its receiver", ep->rank);
+                    return -1;
                 }
             }
             L3K_HIP(hipStreamWaitEvent(stream, msg->done, 0));
@@ -646,7 +700,18 @@ int l3k_mf_apply_dist(l3k_mf* mf, l3k_halo* h, const double* d_x, size_t ldx, do
     }
     // a rank that owns nothing (no element, no node, no neighbour: tests/EmptyPartitionTest.cpp) takes part and returns
     if (mf->mesh->n_elems == 0 && mf->mesh->n_owned_nodes == 0 && mf->mesh->n_ghost_nodes == 0 && h->nbrs.empty())
+    {
+        // (its timing slot is filled like everybody's -- three launches of no duration -- so that l3k_halo_timing_get(i) means
+        // the same apply on every rank)
+        if (h->timing_n < h->timing_cap)
+        {
+            L3K_HIP(hipSetDevice(h->ctx->device));
+            hipEvent_t* tev = &h->timing[size_t(6) * h->timing_n++];
+            for (int k = 0; k < 6; ++k)
+                L3K_HIP(hipEventRecord(tev[k], mf->ctx->stream));
+        }
         return 0;
+    }
     if (!d_x || !d_y)
     {
         setError("l3k_mf_apply_dist: null vector");

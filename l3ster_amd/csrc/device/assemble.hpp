@@ -33,6 +33,13 @@ constexpr int coeffStride()
 }
 
 template < typename K, int P, int NQ >
+constexpr size_t coeffLdsBytes()
+{
+    constexpr int M = cmax(P + 1, NQ);
+    return sizeof(double) * (size_t(5 * K::params.n_fields) * M * M * M + 24);
+}
+// GS: the field buffers in the workgroup's slice of a.scratch instead of the LDS, persistent workgroups (sumfact_apply.hpp)
+template < typename K, int P, int NQ, bool GS = false >
 __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel(const ElemArgs a, const K kern, double* __restrict__ cbuf)
 {
     constexpr KernelParams params = K::params;
@@ -43,10 +50,12 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel
     using Iface = KernelInterface< KernelParams{params.dimension, E, U, F, 1} >;
 
     extern __shared__ double lds[];
-    double* const            Fv = lds;              // fields at the QPs: values, 3 reference derivatives, 1 temp
+    double* const            Fv = GS ? a.scratch + size_t(blockIdx.x) * (coeffLdsBytes< K, P, NQ >() / sizeof(double)) : lds; // fields at the QPs: values, 3 reference derivatives, 1 temp
     double* const            vs = Fv + 5 * F * M3;  // [8][3]
     const int                tid = threadIdx.x;
-    const int64_t            el  = blockIdx.x;      // element within the batch
+    int64_t                  el  = blockIdx.x;      // element within the batch
+    do
+    {
     const int64_t            e   = a.elem_begin + el;
     const uint32_t*          en  = a.elem_nodes + e * NN;
     if (tid < 24)
@@ -116,6 +125,9 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel
         if (!(det > 0.)) // reference: "Encountered degenerate element ( |J| <= 0 )" (AssembleLocalSystem.hpp:249)
             a.workspace[int64_t(a.elem_count) * NQP * CS] = 1.;
     }
+    if constexpr (GS)
+        __syncthreads();
+    } while (GS && (el += gridDim.x) < a.elem_count);
 }
 
 template < int P, int NQ, int U, int E >
@@ -1203,10 +1215,10 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
     K kern{};
     if (kparam_blob)
         __builtin_memcpy(&kern, kparam_blob, sizeof(K));
-    constexpr int M   = cmax(P + 1, NQ);
-    const size_t  ldc = sizeof(double) * (size_t(5 * K::params.n_fields) * M * M * M + 24);
-    auto          kc  = assembleCoeffKernel< K, P, NQ >;
-    auto          kg  = assembleGemmKernel< K, P, NQ >;
+    constexpr size_t ldc    = coeffLdsBytes< K, P, NQ >();
+    constexpr bool   coef_gs = ldc > lds_limit_bytes; // the field buffers of the coefficient kernel exceed the LDS: global scratch
+    auto             kc  = assembleCoeffKernel< K, P, NQ, coef_gs >;
+    auto             kg  = assembleGemmKernel< K, P, NQ >;
     // the dynamic-LDS attributes of the three kernels are set once PER DEVICE, under a lock (several contexts of one
     // process may sit on different GPUs)
     using S = SfAsmCfg< P, NQ >;
@@ -1223,7 +1235,7 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         std::lock_guard< std::mutex > lock{attr_mutex};
         if (!attr_set[dev])
         {
-            bool ok = hipFuncSetAttribute(reinterpret_cast< const void* >(kc), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldc)) == hipSuccess &&
+            bool ok = (coef_gs || hipFuncSetAttribute(reinterpret_cast< const void* >(kc), hipFuncAttributeMaxDynamicSharedMemorySize, int(ldc)) == hipSuccess) &&
                       hipFuncSetAttribute(reinterpret_cast< const void* >(kg), hipFuncAttributeMaxDynamicSharedMemorySize, int(C::lds)) == hipSuccess;
             if constexpr (S::feasible)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
@@ -1243,7 +1255,21 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
         }
     }
     double* cbuf = a.workspace; // coeffStride * nq^3 doubles per element, + 1 flag
-    hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
+    if constexpr (coef_gs)
+    {
+        const int64_t  max_wgs = 2 * int64_t(deviceComputeUnits());
+        const unsigned grid    = static_cast< unsigned >(a.elem_count < max_wgs ? a.elem_count : max_wgs);
+        ElemArgs       ag      = a;
+        ag.scratch             = a.scratch_alloc ? a.scratch_alloc(a.scratch_owner, ldc * grid) : nullptr;
+        if (!ag.scratch)
+        {
+            setError("could not obtain %zu bytes of global scratch for the assembly coefficient kernel", ldc * grid);
+            return -3;
+        }
+        hipLaunchKernelGGL(kc, dim3(grid), dim3(applyThreads< P, NQ >()), 0, stream, ag, kern, cbuf);
+    }
+    else
+        hipLaunchKernelGGL(kc, dim3(static_cast< unsigned >(a.elem_count)), dim3(applyThreads< P, NQ >()), ldc, stream, a, kern, cbuf);
     // the sum-factorised kernel unless it does not fit or l3k_tuning::assemble_dense asks for the dense MFMA product (cross-check)
     const l3k_tuning& tune  = tuneOf(a);
     const bool        dense = !S::feasible || (tune.assemble_dense && !a.K_tiled);

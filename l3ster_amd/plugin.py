@@ -28,7 +28,7 @@ KIND = {"domain": 0, "boundary": 1, "residual": 2}
 _loaded = {}
 
 
-def compile_kernel(type_name, source, kernel_id, shapes, kind="domain", display_name=None, verbose=False):
+def compile_kernel(type_name, source, kernel_id, shapes, kind="domain", display_name=None, verbose=False, isa_scan=True):
     """shapes: (order, nq, ncols) for equation kernels, (order, nq) for residual kernels.  Returns kernel_id."""
     if kernel_id < 1000:
         raise capi.L3KError("plugin kernel ids start at 1000 (lower ids belong to the kernels compiled into libl3k.so)")
@@ -62,14 +62,25 @@ def compile_kernel(type_name, source, kernel_id, shapes, kind="domain", display_
                                                           f"-Wl,-rpath,{libdir}"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise capi.L3KError(f"kernel plugin failed to compile:\n{r.stderr[-4000:]}")
-        # the assembly kernels of a plugin carry the library's hand-written DPP instructions: the same ISA scan as for libl3k.so
-        from . import isa_check
-        if os.path.exists(isa_check.OBJDUMP):
-            _, bad = isa_check.check_dpp_hazards(so + ".tmp")
-            if bad:
+            if os.path.exists(so + ".tmp"):
                 os.unlink(so + ".tmp")
-                raise capi.L3KError(f"kernel plugin: DPP hazard in the generated code, refusing to load it: {bad[:3]}")
+            raise capi.L3KError(f"kernel plugin failed to compile:\n{r.stderr[-4000:]}")
+        # the assembly kernels of a plugin carry the library's hand-written DPP instructions: the same ISA scan as for libl3k.so,
+        # BEFORE the library is loaded.  A plugin that cannot be scanned (no gfx950 code object found, a compressed bundle, no
+        # llvm-objdump) is refused unless the caller waived the scan (isa_scan=False)
+        if isa_scan:
+            from . import isa_check
+            try:
+                report = isa_check.scan(so + ".tmp")
+            except isa_check.IsaScanError as exc:
+                os.unlink(so + ".tmp")
+                raise capi.L3KError(f"kernel plugin: the DPP hazard scan could not run ({exc}); refusing to load an unscanned plugin "
+                                    "(compile_kernel(..., isa_scan=False) loads it anyway)") from None
+            if report["hazards"]:
+                os.unlink(so + ".tmp")
+                raise capi.L3KError(f"kernel plugin: DPP hazard in the generated code, refusing to load it: {report['hazards'][:3]}")
+            if verbose:
+                print(f"[l3k plugin] ISA scan: {report['n_code_objects']} gfx950 code object(s), {report['n_dpp']} DPP instructions, no hazard")
         os.replace(so + ".tmp", so)
         if verbose:
             print(f"[l3k plugin] built {so}")

@@ -38,6 +38,39 @@ def test_hand_written_dpp_instructions_have_no_hazards():
     assert not bad, bad[:5]
 
 
+def test_isa_scan_follows_branches_and_refuses_what_it_cannot_read(tmp_path, monkeypatch):
+    """the scan (a) used to pass when it found no gfx950 code object at all (a compressed bundle, another layout),
+    (b) did not look across loop back-edges: a VALU write of a DPP source at a loop's tail is a hazard for a DPP read at the head."""
+    from l3ster_amd import isa_check
+    junk = tmp_path / "not_a_library.so"
+    junk.write_bytes(b"\x7fELF" + b"CCOB" + bytes(200))
+    with pytest.raises(isa_check.IsaScanError, match="compressed offload bundle"):
+        isa_check.scan(str(junk))
+    junk.write_bytes(b"\x7fELF" + bytes(200))
+    with pytest.raises(isa_check.IsaScanError, match="no gfx950 code object"):
+        isa_check.check_dpp_hazards(str(junk))
+    # a loop: head at 0x100 reads v[4:5] through DPP, the tail writes v[4:5] and branches back (simm16 = -7 dwords from 0x11c)
+    listing = """
+0000000000000100 <loop_kernel>:
+\tv_fmac_f64_dpp v[0:1], v[4:5], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf // 000000000100: 00000000 00000000
+\tv_add_f64 v[6:7], v[0:1], v[2:3]                          // 000000000108: 00000000 00000000
+\ts_nop 0                                                   // 000000000110: BF800000
+\tv_mov_b32_e32 v4, v8                                      // 000000000114: 7E080308
+\ts_cbranch_scc1 65529                                      // 000000000118: BF85FFF9 <loop_kernel>
+\ts_endpgm                                                  // 00000000011C: BF810000
+"""
+    monkeypatch.setattr(isa_check, "code_objects", lambda path: iter([b"x"]))
+    monkeypatch.setattr(isa_check, "_disassemble", lambda co: listing)
+    junk.write_bytes(b"anything")
+    r = isa_check.scan(str(junk))
+    assert r["n_dpp"] == 1 and len(r["hazards"]) == 1 and "across the branch" in r["hazards"][0][2], r
+    # the same loop with two wait states between the write and the branch is clean
+    monkeypatch.setattr(isa_check, "_disassemble", lambda co: listing.replace("\tv_mov_b32_e32 v4, v8 ", "\tv_mov_b32_e32 v4, v8 ").replace(
+        "\ts_cbranch_scc1 65529                                      // 000000000118: BF85FFF9 <loop_kernel>",
+        "\ts_nop 1                                                   // 000000000118: BF800001\n\ts_cbranch_scc1 65528                                      // 00000000011C: BF85FFF8 <loop_kernel>"))
+    assert isa_check.scan(str(junk))["hazards"] == []
+
+
 def test_tables_match_oracle_and_golden(golden):
     g = golden("tables")
     for p in range(1, 9):

@@ -16,7 +16,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
 import oracle_lib as O  # noqa: E402
-from helpers import oracle_mesh  # noqa: E402
+from helpers import oracle_mesh, rel_err  # noqa: E402
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -243,3 +243,66 @@ def test_halo_of_another_context_is_rejected():
     X = dev(part.synthetic_vector(U))
     with pytest.raises(capi.L3KError, match="different contexts"):
         op.apply(X, torch.zeros_like(X))
+
+
+def test_failed_send_closes_the_transport_group():
+    """a failed send / recv after group_begin returned without group_end, leaving e.g. an RCCL group open.  A host-written
+    table (one rank exchanging with itself: a cube made periodic in x) whose send fails on its second call: the error reaches the
+    caller, group_end was called for the group that had been begun, and after the transport recovers the same halo works again."""
+    import ctypes as C
+    from helpers import PeriodicXPartition
+    from l3ster_amd import capi, system
+    from l3ster_amd.distributed import NativeDistributedOperator, NativeHalo
+    torch.cuda.set_device(0)
+    c = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    part = PeriodicXPartition(system.CubePartition((4, 2, 2), 2, perturb=0.1))
+    calls = dict(begin=0, end=0, send=0, fail_at=2)
+    pend, inbox = [], []
+    hip = C.CDLL("libamdhip64.so")
+
+    def begin(_u):
+        calls["begin"] += 1
+        pend.clear()
+        return 0
+
+    def send(_u, buf, n, peer, stream):
+        calls["send"] += 1
+        if calls["send"] == calls["fail_at"]:
+            return -3
+        torch.cuda.ExternalStream(stream).synchronize()
+        t = torch.empty(n, dtype=torch.float64, device="cuda")
+        assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(buf), C.c_size_t(8 * n), 3) == 0
+        inbox.append(t)
+        return 0
+
+    def recv(_u, buf, n, peer, stream):
+        pend.append((buf, n))
+        return 0
+
+    def end(_u, stream):
+        calls["end"] += 1
+        if len(inbox) == len(pend):  # (a complete group: deliver; an abandoned one: drop what was posted)
+            for (buf, n), t in zip(pend, inbox):
+                assert hip.hipMemcpy(C.c_void_p(buf), C.c_void_p(t.data_ptr()), C.c_size_t(8 * n), 3) == 0
+        inbox.clear()
+        return 0
+
+    T = capi.HaloTransport
+    tab = T(None, T.GROUP_BEGIN(begin), T.SEND(send), T.RECV(recv), T.GROUP_END(end), T.DESTROY())
+    mask = np.zeros(part.n_local_nodes * U, np.uint8)
+    n_owned = part.n_owned_nodes * U
+    X = dev(np.random.default_rng(0).uniform(-1, 1, (2, n_owned)))  # two columns: two sends per group
+    Y = torch.zeros_like(X)
+    mf2 = system.MatrixFreeSystem(system.DeviceMesh(c, part, U, mask), KID, KPAR, n_rhs=2)
+    op2 = NativeDistributedOperator(mf2, NativeHalo(c, part, U, 0, 1, transport=tab))
+    with pytest.raises(capi.L3KError):
+        op2.apply(X, Y)
+    assert calls["begin"] == calls["end"] == 1 and calls["send"] == 2
+    calls["fail_at"] = -1
+    Y = torch.zeros_like(X)
+    op2.apply(X, Y)
+    torch.cuda.current_stream().synchronize()
+    assert calls["begin"] == calls["end"] == 3  # import + export of the good apply
+    om = O.MeshView(3, 2, 3, part.merged, part.elem_verts, part.n_owned_nodes, U, np.arange(U), None)
+    y_ref = O.mf_apply(om, KID, X.cpu().numpy().T, kparams=KPAR)
+    assert rel_err(Y.cpu().numpy().T, y_ref) < 1e-11
