@@ -120,7 +120,7 @@ int l3k_ctx_set_reference_z0(l3k_ctx* ctx, int on);
 /* Launch-route settings of a context.  The defaults are what the measurements recorded in DESIGN.md chose; the fields exist so
  * that tests and tools can take the other route ON PURPOSE.  The environment is consulted once, in l3k_ctx_create
  * (L3K_GENERIC_BELOW, L3K_FAST_STATIC, L3K_FAST_WAVES_PER_CU, L3K_NO_AFFINE, L3K_COLUMN_BY_COLUMN, L3K_ASSEMBLE_DENSE,
- * L3K_ASM_TWO_LAUNCHES, L3K_SCATTER_PER_ENTRY initialise the fields below, L3K_DETERMINISTIC the deterministic mode): nothing on the
+ * L3K_ASM_TWO_LAUNCHES, L3K_SCATTER_PER_ENTRY, L3K_ASM_DIRECT_STORE, L3K_ASM_NO_SYMMETRISE initialise the fields below, L3K_DETERMINISTIC the deterministic mode): nothing on the
  * launch path reads the environment, and l3k_mf_route names the kernel a launch takes. */
 typedef struct
 {
@@ -132,6 +132,11 @@ typedef struct
     int     assemble_dense;        /* LocalAssembly as the dense FP64-MFMA product instead of the sum-factorised kernels; 0     */
     int     assemble_two_launches; /* stored row-major LocalAssembly as two launches (diagonal / off-diagonal blocks); 0        */
     int     scatter_per_entry;     /* l3k_assembled_scatter: one wave per row with a search per entry (round-2 kernel); 0       */
+    int     assemble_direct_store; /* stored row-major LocalAssembly written by the assembly kernel itself (8-byte stores at a
+                                      32-byte stride, 3.9 x write traffic) instead of tiled + transposition kernel; 0           */
+    int     assemble_sub_batch;    /* stored row-major LocalAssembly: elements per pipelined sub-batch, 0 = chosen by size; 0      */
+    int     assemble_no_symmetrise; /* stored row-major LocalAssembly without the pass that mirrors the lower triangle: K_e then
+                                      symmetric to rounding (1e-13) instead of bit for bit like the reference's; 0              */
 } l3k_tuning;
 int l3k_ctx_get_tuning(const l3k_ctx* ctx, l3k_tuning* out);
 int l3k_ctx_set_tuning(l3k_ctx* ctx, const l3k_tuning* in);

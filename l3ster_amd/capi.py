@@ -82,7 +82,7 @@ class Tuning(C.Structure):
     """l3k_tuning: the launch-route settings of a context (include/l3k.h)"""
     _fields_ = [("generic_below", C.c_int64), ("static_deal", C.c_int), ("waves_per_cu", C.c_int), ("no_affine", C.c_int),
                 ("column_by_column", C.c_int), ("assemble_dense", C.c_int), ("assemble_two_launches", C.c_int),
-                ("scatter_per_entry", C.c_int)]
+                ("scatter_per_entry", C.c_int), ("assemble_direct_store", C.c_int), ("assemble_sub_batch", C.c_int), ("assemble_no_symmetrise", C.c_int)]
 
 
 # every symbol include/l3k.h declares: (name, restype, argtypes)

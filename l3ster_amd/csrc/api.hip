@@ -686,6 +686,8 @@ int l3k_ctx_create(int hip_device, void* hip_stream, l3k_ctx** out)
     flag("L3K_ASSEMBLE_DENSE", ctx->tune.assemble_dense);
     flag("L3K_ASM_TWO_LAUNCHES", ctx->tune.assemble_two_launches);
     flag("L3K_SCATTER_PER_ENTRY", ctx->tune.scatter_per_entry);
+    flag("L3K_ASM_DIRECT_STORE", ctx->tune.assemble_direct_store);
+    flag("L3K_ASM_NO_SYMMETRISE", ctx->tune.assemble_no_symmetrise);
     // the context's own device buffers are allocated here, with its device current: a later call may come from a thread
     // whose current device is another one (several contexts in one process: thread-emulated ranks, a multi-GPU C++ host)
     if (hipMalloc(reinterpret_cast< void** >(&ctx->work_counters), 9 * 128) != hipSuccess ||
@@ -1414,6 +1416,93 @@ int l3k_mf_dirichlet_finalize(l3k_mf* mf, const double* d_dirichlet_vals, size_t
     return 0;
 }
 
+// K_e of [first, first + count) into d_K (row-major) through the tiled layout: sub-batches formed on the context's stream into one
+// of the system's two buffers, turned on the second stream (events order the reuse of the buffers, as in l3k_assemble_global)
+static int assembleRowMajorViaTiled(l3k_mf* mf, const l3k::dev::Instance* inst, int64_t first, int64_t count, double* d_K)
+{
+    const l3k_mesh* m  = mf->mesh;
+    const int       N1 = m->order + 1, U = mf->kp.n_unknowns, Nd = N1 * N1 * N1 * U;
+    const size_t    mat = size_t(Nd) * Nd; // doubles per matrix
+    // sub-batches of <= 512 MiB of tiled matrices per buffer, at least four per call where that leaves full launches
+    int64_t nb = int64_t((size_t(512) << 20) / (mat * sizeof(double)));
+    nb         = nb < 1 ? 1 : nb;
+    if (const int64_t quarter = (count + 3) / 4; nb > quarter && quarter >= 16)
+        nb = quarter;
+    if (mf->ctx->tune.assemble_sub_batch > 0)
+        nb = mf->ctx->tune.assemble_sub_batch;
+    nb = nb > count ? count : nb;
+    const size_t kd = size_t(nb) * mat, wd = inst->assemble_ws_doubles * size_t(nb) + 1;
+    auto&        g  = mf->gasm;
+    L3K_HIP(hipSetDevice(mf->ctx->device));
+    if (g.doubles < kd + wd)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            if (g.buf[k])
+                L3K_HIP(hipFree(g.buf[k]));
+            g.buf[k] = nullptr;
+        }
+        g.doubles = 0;
+        for (int k = 0; k < 2; ++k)
+            L3K_HIP(hipMalloc(reinterpret_cast< void** >(&g.buf[k]), (kd + wd) * sizeof(double)));
+        g.doubles = kd + wd;
+    }
+    if (!g.second)
+    {
+        L3K_HIP(hipStreamCreateWithFlags(&g.second, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k)
+        {
+            L3K_HIP(hipEventCreateWithFlags(&g.formed[k], hipEventDisableTiming));
+            L3K_HIP(hipEventCreateWithFlags(&g.consumed[k], hipEventDisableTiming));
+        }
+    }
+    hipStream_t sa   = mf->ctx->stream;
+    const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
+    for (int k = 0; k < 2; ++k) // (the flags of degenerate elements: the trailing double of each coefficient workspace)
+        L3K_HIP(hipMemsetAsync(g.buf[k] + kd + inst->assemble_ws_doubles * size_t(nb), 0, sizeof(double), sa));
+    int64_t done  = 0;
+    int     n_sub = 0;
+    for (int i = 0; done < count; ++i, ++n_sub)
+    {
+        const int     k = i & 1;
+        const int64_t n = count - done < nb ? count - done : nb;
+        if (i >= 2)
+            L3K_HIP(hipStreamWaitEvent(sa, g.consumed[k], 0)); // the transposition of sub-batch i - 2 has read this buffer
+        l3k::dev::ElemArgs a;
+        if (int rc = fillArgs(mf, 2, mf->n_rhs, a))
+            return rc;
+        a.elem_begin     = first + done;
+        a.elem_count     = n;
+        a.elem_begin_out = 0;
+        a.K              = g.buf[k];
+        a.K_tiled        = 1;
+        a.workspace      = g.buf[k] + kd + size_t(nb - n) * inst->assemble_ws_doubles; // (the flag keeps one position per buffer)
+        if (int rc = inst->assemble(a, blob, sa))
+            return rc;
+        L3K_HIP(hipEventRecord(g.formed[k], sa));
+        L3K_HIP(hipStreamWaitEvent(g.second, g.formed[k], 0));
+        if (int rc = launchTiledToRowMajor(U, N1, n, g.buf[k], d_K + size_t(done) * mat, g.second))
+            return rc;
+        if (!mf->ctx->tune.assemble_no_symmetrise) // (bitwise symmetric matrices, as the reference returns them)
+            if (int rc = launchSymmetrise(Nd, n, d_K + size_t(done) * mat, g.second))
+                return rc;
+        L3K_HIP(hipEventRecord(g.consumed[k], g.second));
+        done += n;
+    }
+    for (int k = 0; k < 2 && k < n_sub; ++k)
+        L3K_HIP(hipStreamWaitEvent(sa, g.consumed[k], 0)); // later work on the context's stream sees the finished matrices
+    double flags[2] = {0., 0.};
+    for (int k = 0; k < 2; ++k)
+        L3K_HIP(hipMemcpyAsync(&flags[k], g.buf[k] + kd + inst->assemble_ws_doubles * size_t(nb), sizeof(double), hipMemcpyDeviceToHost, sa));
+    L3K_HIP(hipStreamSynchronize(sa));
+    if (flags[0] != 0. || flags[1] != 0.)
+    {
+        setError("Encountered degenerate element ( |J| <= 0 )"); // algsys/AssembleLocalSystem.hpp:249
+        return -2;
+    }
+    return 0;
+}
+
 int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum)
 {
     if (!mf)
@@ -1443,7 +1532,19 @@ int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, do
     a.checksum       = d_checksum;
     hipStream_t s    = mf->ctx->stream;
     const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
-    if (d_K || d_checksum)
+    // Stored row-major matrices: formed in the tiled layout (coalesced stores) and turned by a transposition kernel on a second
+    // stream, sub-batch by sub-batch -- the assembly kernels cannot fill the 64-byte lines of a row-major K_e (four workgroups and
+    // two iterations per line: 3.9 x write traffic).  l3k_tuning::assemble_direct_store keeps the direct store (cross-check).
+    const l3k_tuning& tune = mf->ctx->tune;
+    const bool via_tiled = d_K && inst->assemble_tiled && mf->kp.n_unknowns <= 4 && m->order <= 7 && !tune.assemble_dense &&
+                           !tune.assemble_two_launches && !tune.assemble_direct_store;
+    if (via_tiled)
+    {
+        if (int rc = assembleRowMajorViaTiled(mf, inst, first, count, d_K))
+            return rc;
+        a.K = nullptr; // (a checksum asked for beside K comes from a streaming pass below)
+    }
+    if (a.K || d_checksum)
     {
         const size_t need = inst->assemble_ws_doubles * size_t(count) + 1;
         if (need > mf->ws_doubles)

@@ -256,6 +256,129 @@ int launchScatterTiled(const ScatterArgs& a, int N1, int64_t blocks, hipStream_t
 }
 } // namespace
 
+// Tiled layout -> the reference's row-major K_e (AssembleLocalSystem.hpp:168-182).  The assembly kernels cannot store row-major
+// efficiently -- a 64-byte line of K_e holds the entries of four unknown pairs (u, u') and two b_x', i.e. of four workgroups and two
+// iterations: 3.9 x write traffic, 22 % full requests (profiles/r03_tcc_assembly_stored.txt) -- so the stored mode forms the tiled
+// layout (coalesced) and THIS kernel turns it: one workgroup per (element, row node b) reads the U * U * n runs of n^2 doubles that
+// belong to the node's U rows (392-byte runs at order 6), keeps them in LDS in read order and writes the U rows -- adjacent rows of
+// the row-major matrix, one contiguous block of U * Nd doubles -- with consecutive lanes on consecutive addresses: whole 64-byte
+// lines only.
+template < int U, int N1 >
+__global__ __launch_bounds__(256) void tiledToRowMajorKernel(const double* __restrict__ Kt, double* __restrict__ K)
+{
+    constexpr int N2 = N1 * N1, NN = N2 * N1, Nd = NN * U, TOTAL = U * U * N1 * N2; // (= U * Nd)
+    extern __shared__ double rowbuf[];                                           // [u][u'][bx'][by' * N1 + bz']: read order
+    const int64_t  e  = blockIdx.x / NN;
+    const int      b  = int(blockIdx.x - e * NN);
+    const int      bx = b % N1, by = (b / N1) % N1, bz = b / N2;
+    const double*  Ke = Kt + e * int64_t(Nd) * Nd;
+    for (int t = threadIdx.x; t < TOTAL; t += 256)
+    {
+        const int j = t % N2, r = t / N2, bxp = r % N1, uu = r / N1; // uu = u * U + u'
+        rowbuf[t]   = Ke[((((int64_t(uu) * N1 + bxp) * N1 + bz) * N1 + bx) * N1 + by) * N2 + j];
+    }
+    __syncthreads();
+    double* out = K + e * int64_t(Nd) * Nd + int64_t(b) * U * Nd; // rows (b, 0 .. U-1)
+    for (int o = threadIdx.x; o < TOTAL; o += 256)
+    {
+        const int u = o / Nd, gj = o - u * Nd, up = gj % U, bp = gj / U;
+        const int bxp = bp % N1, byp = (bp / N1) % N1, bzp = bp / N2;
+        out[o]        = rowbuf[((u * U + up) * N1 + bxp) * N2 + byp * N1 + bzp];
+    }
+}
+template < int U >
+int launchTiledToRowMajorU(int N1, int64_t blocks, const double* Kt, double* K, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * size_t(U) * U * N1 * N1 * N1;
+    switch (N1)
+    {
+    case 2: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 2 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 3: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 3 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 4: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 4 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 5: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 5 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 6: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 6 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 7: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 7 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    case 8: hipLaunchKernelGGL((tiledToRowMajorKernel< U, 8 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K); break;
+    default: return 1;
+    }
+    return 0;
+}
+// K_e <- its lower triangle mirrored (the reference's getSystem: selfadjointView copy, AssembleLocalSystem.hpp:176-182): the tiled
+// kernel forms K[i][j] and K[j][i] in two different summation orders (equal to rounding); the reference's matrix is symmetric
+// bit for bit.  One workgroup per pair of 64 x 64 tiles (I > J): tile (I, J) read with coalesced rows, turned in LDS, written to
+// (J, I) with coalesced rows; diagonal tiles mirror themselves.
+__global__ __launch_bounds__(256) void symmetriseKernel(double* __restrict__ K, int Nd)
+{
+    constexpr int    T = 64;
+    __shared__ double tile[T][T + 1];
+    const int nt    = (Nd + T - 1) / T, npairs = nt * (nt + 1) / 2;
+    const int64_t e = blockIdx.x / npairs;
+    int       rem   = int(blockIdx.x - e * npairs), ti = 0; // lower-triangular tile index -> (ti, tj <= ti)
+    while (rem > ti)
+    {
+        rem -= ti + 1;
+        ++ti;
+    }
+    const int tj = rem;
+    double*   Ke = K + e * int64_t(Nd) * Nd;
+    const int c = threadIdx.x & (T - 1), r0 = threadIdx.x >> 6; // 4 rows per pass
+    for (int r = r0; r < T; r += 4)
+    {
+        const int gi = ti * T + r, gj = tj * T + c;
+        if (gi < Nd && gj < Nd)
+            tile[r][c] = Ke[int64_t(gi) * Nd + gj];
+    }
+    __syncthreads();
+    for (int r = r0; r < T; r += 4)
+    {
+        const int gi = tj * T + r, gj = ti * T + c; // entry (gi, gj) of the mirrored tile <- tile[c][r] = K[gj][gi]
+        if (gi < Nd && gj < Nd && gj > gi)
+            Ke[int64_t(gi) * Nd + gj] = tile[c][r];
+    }
+}
+// `count` element matrices: tiled (d_Kt) -> row-major (d_K), on stream s
+int launchSymmetrise(int Nd, int64_t count, double* d_K, hipStream_t s)
+{
+    const int     nt     = (Nd + 63) / 64;
+    const int64_t blocks = count * (int64_t(nt) * (nt + 1) / 2);
+    if (blocks > int64_t(0x7fffffff))
+    {
+        setError("symmetrise: batch too large");
+        return -1;
+    }
+    hipLaunchKernelGGL(symmetriseKernel, dim3(unsigned(blocks)), dim3(256), 0, s, d_K, Nd);
+    if (hipGetLastError() != hipSuccess)
+    {
+        setError("symmetrise kernel launch failed");
+        return -3;
+    }
+    return 0;
+}
+int launchTiledToRowMajor(int U, int N1, int64_t count, const double* d_Kt, double* d_K, hipStream_t s)
+{
+    const int64_t blocks = count * N1 * N1 * N1;
+    if (blocks > int64_t(0x7fffffff) || U < 1 || U > 4 || size_t(U) * U * N1 * N1 * N1 * sizeof(double) > 64 * 1024)
+    {
+        setError("tiled -> row-major: shape (order %d, %d unknowns, %lld elements) not supported", N1 - 1, U, (long long)count);
+        return -1;
+    }
+    int rc = 1;
+    switch (U)
+    {
+    case 1: rc = launchTiledToRowMajorU< 1 >(N1, blocks, d_Kt, d_K, s); break;
+    case 2: rc = launchTiledToRowMajorU< 2 >(N1, blocks, d_Kt, d_K, s); break;
+    case 3: rc = launchTiledToRowMajorU< 3 >(N1, blocks, d_Kt, d_K, s); break;
+    case 4: rc = launchTiledToRowMajorU< 4 >(N1, blocks, d_Kt, d_K, s); break;
+    default: break;
+    }
+    if (rc || hipGetLastError() != hipSuccess)
+    {
+        setError("tiled -> row-major kernel launch failed (order %d, %d unknowns)", N1 - 1, U);
+        return -3;
+    }
+    return 0;
+}
+
 // the launch of the batch scatter on `s` (shared by l3k_assembled_scatter and the pipelined l3k_assemble_global)
 int launchAssembledScatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
                            const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet,

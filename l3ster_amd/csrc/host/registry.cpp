@@ -55,7 +55,7 @@ int deviceComputeUnits()
 const l3k_tuning& defaultTuning()
 {
     static const l3k_tuning t{.generic_below = 1500, .static_deal = 0, .waves_per_cu = 0, .no_affine = 0, .column_by_column = 0,
-                              .assemble_dense = 0, .assemble_two_launches = 0, .scatter_per_entry = 0};
+                              .assemble_dense = 0, .assemble_two_launches = 0, .scatter_per_entry = 0, .assemble_direct_store = 0, .assemble_sub_batch = 0, .assemble_no_symmetrise = 0};
     return t;
 }
 void registerPluginKernel(const PluginKernel& k)

@@ -347,3 +347,37 @@ def test_rhs_scatter_with_more_than_64_rhs_entries_per_node(ctx, mode):
             rhs = torch.zeros((R, n), dtype=torch.float64, device="cuda")
             mf.assembled_scatter(None, dev(F), None, None, None, rhs, skip_dirichlet=skip)
             np.testing.assert_allclose(rhs.cpu().numpy(), want, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("kid,ne,p,vo,kpar", [(system.KERNEL_DIFFUSION3D, (3, 2, 2), 2, 1, [0.7, 1.3]), (system.KERNEL_DIFFUSION3D, (2, 2, 1), 4, 1, [1.0, 1.0]),
+                                              (system.KERNEL_DIFFUSION3D, (2, 1, 1), 6, 1, [0.7, 1.3]), (system.KERNEL_MASS3D, 2, 3, 2, None),
+                                              (system.KERNEL_DIVCURL3D, (2, 1, 1), 4, 1, [0.6]), (system.KERNEL_ADVECTION3D, 2, 4, 1, [0.05])])
+def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
+    """l3k_local_assemble(K) -- the stand-in for assembleLocalSystem's return value (row-major K_e, AssembleLocalSystem.hpp:168-182) --
+    forms the matrices in the tiled layout and turns them with a transposition kernel on a second stream, sub-batch by sub-batch,
+    then mirrors the lower triangle (round 4; the assembly kernel's own row-major stores fill an eighth of each 64-byte line per
+    instruction).  The routes agree: default == tiled + transposition without the mirror pass to rounding == the direct store to
+    rounding; the default is symmetric bit for bit like the reference's matrix; several sub-batches give the same bits as one."""
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(ne, p, perturb=0.15)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U), kid, kpar, asm_opts=(vo, 0, 0))
+    if F:
+        mf.set_fields(dev(np.random.default_rng(2).uniform(-1, 1, (F, part.n_local_nodes))))
+    K0, _, _ = mf.local_assemble(want_F=False)
+    with ctx.tuning(assemble_sub_batch=3):
+        K1, _, _ = mf.local_assemble(want_F=False)
+    with ctx.tuning(assemble_no_symmetrise=1):
+        K2, _, _ = mf.local_assemble(want_F=False)
+    with ctx.tuning(assemble_direct_store=1):
+        K3, _, _ = mf.local_assemble(want_F=False)
+    torch.cuda.synchronize()
+    scale = float(K3.abs().amax())
+    assert torch.equal(K0, K0.transpose(1, 2)) and torch.equal(K0, K1)
+    assert torch.equal(torch.tril(K0), torch.tril(K2))  # the mirror pass only rewrites the upper triangle
+    assert float((K2 - K2.transpose(1, 2)).abs().amax()) < 1e-13 * scale
+    assert float((K0 - K3).abs().amax()) < 1e-13 * scale and torch.equal(K3, K3.transpose(1, 2))
+    # a sub-range with an offset, and the checksum beside the stored matrices
+    Ks, _, cs = mf.local_assemble(1, part.n_elems - 1, want_F=False, want_checksum=True)
+    _, _, cs_stream = mf.local_assemble(1, part.n_elems - 1, want_K=False, want_F=False, want_checksum=True)
+    assert torch.equal(Ks, K0[1:]) and torch.equal(cs, cs_stream)
