@@ -1536,8 +1536,10 @@ int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, do
     // stream, sub-batch by sub-batch -- the assembly kernels cannot fill the 64-byte lines of a row-major K_e (four workgroups and
     // two iterations per line: 3.9 x write traffic).  l3k_tuning::assemble_direct_store keeps the direct store (cross-check).
     const l3k_tuning& tune = mf->ctx->tune;
+    // (orders >= 4, or on request: below, a matrix is a few KB and the direct store wins -- order 2: 12.9 M against 6.7 M matrices/s,
+    // profiles/r04_stored_assembly.jsonl)
     const bool via_tiled = d_K && inst->assemble_tiled && mf->kp.n_unknowns <= 4 && m->order <= 7 && !tune.assemble_dense &&
-                           !tune.assemble_two_launches && !tune.assemble_direct_store;
+                           !tune.assemble_two_launches && !tune.assemble_direct_store && (m->order >= 4 || tune.assemble_sub_batch > 0);
     if (via_tiled)
     {
         if (int rc = assembleRowMajorViaTiled(mf, inst, first, count, d_K))

@@ -373,10 +373,12 @@ def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
         K3, _, _ = mf.local_assemble(want_F=False)
     torch.cuda.synchronize()
     scale = float(K3.abs().amax())
-    assert torch.equal(K0, K0.transpose(1, 2)) and torch.equal(K0, K1)
-    assert torch.equal(torch.tril(K0), torch.tril(K2))  # the mirror pass only rewrites the upper triangle
+    # (the default route: tiled + transposition from order 4, the direct store below -- small matrices)
+    assert torch.equal(K0, K1 if p >= 4 else K3)
+    assert torch.equal(K1, K1.transpose(1, 2)) and torch.equal(K3, K3.transpose(1, 2))
+    assert torch.equal(torch.tril(K1), torch.tril(K2))  # the mirror pass only rewrites the upper triangle
     assert float((K2 - K2.transpose(1, 2)).abs().amax()) < 1e-13 * scale
-    assert float((K0 - K3).abs().amax()) < 1e-13 * scale and torch.equal(K3, K3.transpose(1, 2))
+    assert float((K1 - K3).abs().amax()) < 1e-13 * scale
     # a sub-range with an offset, and the checksum beside the stored matrices
     Ks, _, cs = mf.local_assemble(1, part.n_elems - 1, want_F=False, want_checksum=True)
     _, _, cs_stream = mf.local_assemble(1, part.n_elems - 1, want_K=False, want_F=False, want_checksum=True)
