@@ -50,7 +50,7 @@ def algorithmic_bytes_per_dof(p, U, F=0):
 
 KERNEL_SOURCES = ("l3ster_amd/csrc/device/sumfact_fast.hpp", "l3ster_amd/csrc/device/sumfact_apply.hpp",
                   "l3ster_amd/csrc/device/common.hpp", "l3ster_amd/csrc/user_kernels.hpp", "include/l3k/kernel_interface.hpp")
-TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
 
 
 def kernel_source_hash():

@@ -137,7 +137,30 @@ if os.path.isdir(os.path.join(SRC, "o6_tcc")):
     write_counters(os.path.join(DST, f"{tag}_tcc_fast_kernel_64cubed.txt"),
                    "# rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_WRREQ_ATOMIC_DRAM TCC_EA0_RDREQ --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline,\n"
                    "# sumfactFastKernel<Diffusion3D,6,7>, 64^3 elements, mean per launch, chip-wide sums\n", m6, n6, 262144)
-if os.path.isdir(os.path.join(SRC, "asm_tcc")):
+if os.path.isdir(os.path.join(SRC, "asm_fetch")):  # round 4: the stored route is three kernels (tools/r04_stored_assembly.py runs all routes)
+    alg = 64 * 1372 * 1372 * 8
+    with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
+        out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE | FETCH_SIZE> --kernel-trace -- python tools/r04_stored_assembly.py --orders 6 --batch 64 --steps 2\n"
+                  "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each, 963.7 MB per batch), row-major, per KERNEL of the routes; mean per launch\n"
+                  "# (direct store = assembleSumfactKernel<..., false, 0> with K; round-4 default = assembleSumfactKernel<..., true, 0> (tiled) + tiledToRowMajorKernel + symmetriseKernel)\n")
+        for label, pred in (("direct row-major store (assembleSumfactKernel<.., false, 0>)", lambda nme: "assembleSumfactKernel" in nme and "false, 0>" in nme),
+                            ("tiled store (assembleSumfactKernel<.., true, 0>)", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme),
+                            ("tiledToRowMajorKernel", lambda nme: "tiledToRowMajorKernel" in nme),
+                            ("symmetriseKernel", lambda nme: "symmetriseKernel" in nme)):
+            mk, nk = counters_of(["asm_tcc", "asm_write", "asm_fetch"], pred)
+            if not mk:
+                continue
+            out.write(f"## {label}\n")
+            if "WRITE_SIZE" in mk:
+                out.write(f"#   WRITE_SIZE = {mk['WRITE_SIZE'] * 1024 / 1e6:.1f} MB per launch = x{mk['WRITE_SIZE'] * 1024 / alg:.2f} of the matrices' bytes\n")
+            if "FETCH_SIZE" in mk:
+                out.write(f"#   2 x FETCH_SIZE = {2 * mk['FETCH_SIZE'] * 1024 / 1e6:.1f} MB per launch = x{2 * mk['FETCH_SIZE'] * 1024 / alg:.2f}\n")
+            if "TCC_EA0_WRREQ" in mk:
+                out.write(f"#   write requests to memory: {mk['TCC_EA0_WRREQ']:.4g} per launch = {mk['TCC_EA0_WRREQ'] * 64 / alg:.2f} x (matrix bytes / 64); "
+                          f"64-byte ones: {mk.get('TCC_EA0_WRREQ_64B', 0):.4g} ({100 * mk.get('TCC_EA0_WRREQ_64B', 0) / mk['TCC_EA0_WRREQ']:.0f} %)\n")
+            for k in sorted(mk):
+                out.write(f"{k:28s} n={nk[k]} mean={mk[k]:.4g}\n")
+elif os.path.isdir(os.path.join(SRC, "asm_tcc")):
     ma, na = counters_of(["asm_tcc", "asm_write"], lambda name: "assembleSumfactKernel" in name)
     with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
         out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE> --kernel-trace -- python tools/bench_assembly.py --order 6 --store --batch 64: assembleSumfactKernel<Diffusion3D,6,7>\n"
