@@ -141,15 +141,17 @@ if os.path.isdir(os.path.join(SRC, "asm_fetch")):  # round 4: the stored route i
     alg = 64 * 1372 * 1372 * 8
     with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
         out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE | FETCH_SIZE> --kernel-trace -- python tools/r04_stored_assembly.py --orders 6 --batch 64 --steps 2\n"
-                  "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each, 963.7 MB per batch), row-major, per KERNEL of the routes; mean per launch\n"
+                  "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each), row-major, per KERNEL of the routes; mean per launch.  The direct store\n"
+                  "# is one launch over the 64 matrices (963.7 MB); the round-4 route runs as 4 pipelined sub-batches of 16 matrices (240.9 MB per launch)\n"
                   "# (direct store = assembleSumfactKernel<..., false, 0> with K; round-4 default = assembleSumfactKernel<..., true, 0> (tiled) + tiledToRowMajorKernel + symmetriseKernel)\n")
-        for label, pred in (("direct row-major store (assembleSumfactKernel<.., false, 0>)", lambda nme: "assembleSumfactKernel" in nme and "false, 0>" in nme),
-                            ("tiled store (assembleSumfactKernel<.., true, 0>)", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme),
-                            ("tiledToRowMajorKernel", lambda nme: "tiledToRowMajorKernel" in nme),
-                            ("symmetriseKernel", lambda nme: "symmetriseKernel" in nme)):
+        for label, pred, n_mat in (("direct row-major store (assembleSumfactKernel<.., false, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "false, 0>" in nme, 64),
+                                   ("tiled store (assembleSumfactKernel<.., true, 0>), 16 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme, 16),
+                                   ("tiledToRowMajorKernel, 16 matrices per launch", lambda nme: "tiledToRowMajorKernel" in nme, 16),
+                                   ("symmetriseKernel, 16 matrices per launch (reads the lower, writes the upper triangles)", lambda nme: "symmetriseKernel" in nme, 16)):
             mk, nk = counters_of(["asm_tcc", "asm_write", "asm_fetch"], pred)
             if not mk:
                 continue
+            alg = n_mat * 1372 * 1372 * 8
             out.write(f"## {label}\n")
             if "WRITE_SIZE" in mk:
                 out.write(f"#   WRITE_SIZE = {mk['WRITE_SIZE'] * 1024 / 1e6:.1f} MB per launch = x{mk['WRITE_SIZE'] * 1024 / alg:.2f} of the matrices' bytes\n")
