@@ -1423,11 +1423,10 @@ static int assembleRowMajorViaTiled(l3k_mf* mf, const l3k::dev::Instance* inst, 
     const l3k_mesh* m  = mf->mesh;
     const int       N1 = m->order + 1, U = mf->kp.n_unknowns, Nd = N1 * N1 * N1 * U;
     const size_t    mat = size_t(Nd) * Nd; // doubles per matrix
-    // sub-batches of <= 512 MiB of tiled matrices per buffer, at least four per call where that leaves full launches
-    int64_t nb = int64_t((size_t(512) << 20) / (mat * sizeof(double)));
+    // sub-batches of <= 1.5 GiB of tiled matrices per buffer (large launches: the kernels of the route are all memory-bound, so their
+    // overlap on the two streams buys little and small sub-batches only add launch tails: tools/r04_stored_subbatch.py)
+    int64_t nb = int64_t((size_t(1536) << 20) / (mat * sizeof(double)));
     nb         = nb < 1 ? 1 : nb;
-    if (const int64_t quarter = (count + 3) / 4; nb > quarter && quarter >= 16)
-        nb = quarter;
     if (mf->ctx->tune.assemble_sub_batch > 0)
         nb = mf->ctx->tune.assemble_sub_batch;
     nb = nb > count ? count : nb;

@@ -272,10 +272,25 @@ __global__ __launch_bounds__(256) void tiledToRowMajorKernel(const double* __res
     const int      b  = int(blockIdx.x - e * NN);
     const int      bx = b % N1, by = (b / N1) % N1, bz = b / N2;
     const double*  Ke = Kt + e * int64_t(Nd) * Nd;
-    for (int t = threadIdx.x; t < TOTAL; t += 256)
+    // (eight independent loads in flight per thread before the first LDS store: the kernel is a pure memory mover)
+    constexpr int NB = 8;
+    for (int t0 = threadIdx.x; t0 < TOTAL; t0 += 256 * NB)
     {
-        const int j = t % N2, r = t / N2, bxp = r % N1, uu = r / N1; // uu = u * U + u'
-        rowbuf[t]   = Ke[((((int64_t(uu) * N1 + bxp) * N1 + bz) * N1 + bx) * N1 + by) * N2 + j];
+        double v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+        {
+            const int t = t0 + 256 * k;
+            if (t < TOTAL)
+            {
+                const int j = t % N2, r = t / N2, bxp = r % N1, uu = r / N1; // uu = u * U + u'
+                v[k]        = Ke[((((int64_t(uu) * N1 + bxp) * N1 + bz) * N1 + bx) * N1 + by) * N2 + j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (t0 + 256 * k < TOTAL)
+                rowbuf[t0 + 256 * k] = v[k];
     }
     __syncthreads();
     double* out = K + e * int64_t(Nd) * Nd + int64_t(b) * U * Nd; // rows (b, 0 .. U-1)
@@ -322,11 +337,17 @@ __global__ __launch_bounds__(256) void symmetriseKernel(double* __restrict__ K, 
     const int tj = rem;
     double*   Ke = K + e * int64_t(Nd) * Nd;
     const int c = threadIdx.x & (T - 1), r0 = threadIdx.x >> 6; // 4 rows per pass
-    for (int r = r0; r < T; r += 4)
     {
-        const int gi = ti * T + r, gj = tj * T + c;
-        if (gi < Nd && gj < Nd)
-            tile[r][c] = Ke[int64_t(gi) * Nd + gj];
+        double v[T / 4]; // (all sixteen loads of a thread in flight before the first LDS store)
+#pragma unroll
+        for (int k = 0; k < T / 4; ++k)
+        {
+            const int gi = ti * T + r0 + 4 * k, gj = tj * T + c;
+            v[k]         = gi < Nd && gj < Nd ? Ke[int64_t(gi) * Nd + gj] : 0.;
+        }
+#pragma unroll
+        for (int k = 0; k < T / 4; ++k)
+            tile[r0 + 4 * k][c] = v[k];
     }
     __syncthreads();
     for (int r = r0; r < T; r += 4)

@@ -367,7 +367,7 @@ def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
     K0, _, _ = mf.local_assemble(want_F=False)
     with ctx.tuning(assemble_sub_batch=3):
         K1, _, _ = mf.local_assemble(want_F=False)
-    with ctx.tuning(assemble_no_symmetrise=1):
+    with ctx.tuning(assemble_no_symmetrise=1, assemble_sub_batch=3):
         K2, _, _ = mf.local_assemble(want_F=False)
     with ctx.tuning(assemble_direct_store=1):
         K3, _, _ = mf.local_assemble(want_F=False)
@@ -380,6 +380,8 @@ def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
     assert float((K2 - K2.transpose(1, 2)).abs().amax()) < 1e-13 * scale
     assert float((K1 - K3).abs().amax()) < 1e-13 * scale
     # a sub-range with an offset, and the checksum beside the stored matrices
-    Ks, _, cs = mf.local_assemble(1, part.n_elems - 1, want_F=False, want_checksum=True)
+    with ctx.tuning(assemble_sub_batch=2):
+        Ks, _, cs = mf.local_assemble(1, part.n_elems - 1, want_F=False, want_checksum=True)
     _, _, cs_stream = mf.local_assemble(1, part.n_elems - 1, want_K=False, want_F=False, want_checksum=True)
-    assert torch.equal(Ks, K0[1:]) and torch.equal(cs, cs_stream)
+    assert torch.equal(Ks, K1[1:])
+    np.testing.assert_allclose(cs.cpu().numpy(), cs_stream.cpu().numpy(), rtol=1e-12)  # (one atomic add per workgroup: order varies)
