@@ -253,7 +253,14 @@ struct FastCfg
     static constexpr int    DF       = kernelUsesFieldDers< K >() ? NF : U; // fields with derivatives
     static constexpr int    BUF_D    = 2 * NG * OS;                         // buffer A (doubles)
     static constexpr int    BUFB_D   = 2 * DG * OS;                         // buffer B: derivative groups only
-    static constexpr int    TEAM_D   = BUF_D + BUFB_D + 24 + 2; // buffers, 8 vertices, energy accumulator (+ pad)
+    // Fields that enter by value only (DG < NG: the kernel declared field_derivatives = false) are dead in buffer A once the
+    // x interpolation has taken them into registers -- buffer B (first written by the eta-derivative stage, DG groups) then lives in
+    // buffer A's groups [DG, 2 DG): no LDS of its own.  Config 5's kernel (U = 4, F = 3) at order 4: 16.4 instead of 24.4 KB per
+    // wave, 8 instead of 6 waves per CU; the scalar advection kernel (U = 1, F = 3) at order 6: 11.9 instead of 17.4 KB, 12 waves
+    static constexpr bool   ALIAS_B  = DG < NG && NG - DG >= DG;
+    static constexpr int    OFF_B    = ALIAS_B ? 2 * DG * OS : BUF_D;       // buffer B's offset in the team's block (doubles)
+    static constexpr int    OFF_V    = ALIAS_B ? BUF_D : BUF_D + BUFB_D;    // vertices, energy accumulator
+    static constexpr int    TEAM_D   = OFF_V + 24 + 2; // buffers, 8 vertices, energy accumulator (+ pad)
     static constexpr int    SLOT_B   = 16 * N1 * N1; // scatter-slot table of the mesh: [N1*N1 lanes][8] uint16, one copy per wave
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D + SLOT_B;
     static constexpr int    SG       = (64 / EW) / U * U; // lanes that scatter one element (the team's lanes + helpers): a multiple of U
@@ -325,8 +332,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
     constexpr int            SG     = Cfg::SG;
     double* const            base = lds + size_t(worker ? team : 0) * Cfg::TEAM_D;
     double2* const           bufA = reinterpret_cast< double2* >(base);
-    double2* const           bufB = reinterpret_cast< double2* >(base + Cfg::BUF_D);
-    double* const            vs   = base + Cfg::BUF_D + Cfg::BUFB_D; // [8][3]
+    double2* const           bufB = reinterpret_cast< double2* >(base + Cfg::OFF_B);
+    double* const            vs   = base + Cfg::OFF_V; // [8][3]
 
     const double* const eoI  = tab.eoI;
     const double* const eoC  = tab.eoC;
@@ -630,7 +637,8 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 {
                     v[q][2 * g]     = o0[q];
                     v[q][2 * g + 1] = o1[q];
-                    stg(bufA, g, at(q, qa, qb), o0[q], o1[q]);
+                    if (g < DG) // (only the groups whose eta / zeta derivatives are formed go back to LDS)
+                        stg(bufA, g, at(q, qa, qb), o0[q], o1[q]);
                 }
             }
             }
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
         const int steam_s = lane_s / SG, sl = lane_s - steam_s * SG;
         if (steam_s < EW && (int64_t(batch) * EW + steam_s) < a.elem_count)
         {
-            const double* const   sb      = lds + size_t(steam_s) * Cfg::TEAM_D + Cfg::BUF_D;
+            const double* const   sb      = lds + size_t(steam_s) * Cfg::TEAM_D + Cfg::OFF_B;
             const uint32_t* const idsS    = reinterpret_cast< const uint32_t* >(lds + size_t(steam_s) * Cfg::TEAM_D);
             // (Dirichlet dofs were zeroed when the result was staged: every element takes the common path)
 #ifndef L3K_FLAGGED_SCATTER
