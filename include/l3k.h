@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* 101 (round 4): l3k_cg_update_xr / _update_p replaced by l3k_cg_update_z / _update_px (the iteration keeps z = M^-1 r; d_r holds z),
- * new: l3k_ctx_set_reference_z0, l3k_ctx_get/set_tuning, l3k_mf_route */
+ * new: l3k_ctx_set_reference_z0, l3k_ctx_get/set_tuning, l3k_mf_route, l3k_update_solution */
 #define L3K_VERSION 101
 
 typedef struct l3k_ctx      l3k_ctx;
@@ -272,6 +272,14 @@ int l3k_values_at_nodes(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const voi
                         const double* d_fields, size_t ldf, double time, int64_t n_faces, const int64_t* face_elem,
                         const uint8_t* face_side, const int* dof_inds, double* d_sum, double* d_count);
 int l3k_average_values(l3k_ctx* ctx, const double* d_sum, const double* d_count, int64_t n, double* d_values);
+/* MatrixFreeSystem::updateSolution(sol_inds, sol_man, sol_man_inds) (algsys/MatrixFreeSystem.hpp:1231-1273; AlgebraicSystem's
+ * twin): the solution's per-node dofs sol_inds[i] of column r copied into field sol_man_inds[i * ncols + r] of the SoA field
+ * storage a kernel's FieldAccess reads (value(node, f) = d_fields[node + f * ldf], the layout of l3k_mf_set_fields), for EVERY
+ * local node: owned rows from d_x, ghost rows from d_xghost -- the values the reference imports inside updateSolution; a
+ * partitioned host calls l3k_halo_import first (NULL on a rank without ghosts).  Index lists are host arrays.  Errors as the
+ * reference's asserts: "Source index out of bounds" (>= dofs_per_node), "Destination index out of bounds" (>= n_fields). */
+int l3k_update_solution(l3k_ctx* ctx, l3k_mesh* mesh, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, int ncols,
+                        int n_inds, const int* sol_inds, const int* sol_man_inds, double* d_fields, size_t ldf, int n_fields);
 
 /* ---- Jacobi-preconditioned conjugate gradients ------------------------------------------------------------------------
  * The reference hands the iteration to Trilinos Belos ("Block CG", solve/BelosSolvers.hpp:116-122) with its native Jacobi

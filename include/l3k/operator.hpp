@@ -263,6 +263,18 @@ std::vector< double > computeNormL2(const DeviceMesh& mesh, int residual_id, con
 
 // algsys::MatrixFreeSystem for one rank without ghosts.  Kernel = registered functor id + POD parameter block
 // (l3ster_amd/csrc/user_kernels.hpp); vectors are DEVICE pointers, column-major with leading dimension.
+// MatrixFreeSystem::updateSolution(sol_inds, sol_man, sol_man_inds) (algsys/MatrixFreeSystem.hpp:1231-1273): the solution's per-node
+// dofs sol_inds of every column into the fields sol_man_inds (index-major, one per (index, column)) of the SoA field storage that a
+// kernel's FieldAccess reads; ghost rows from d_xghost (the imported values; nullptr on a rank without ghosts)
+inline void updateSolution(const DeviceMesh& mesh, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, int ncols,
+                           std::span< const int > sol_inds, std::span< const int > sol_man_inds, double* d_fields, size_t ldf, int n_fields)
+{
+    if (sol_man_inds.size() != sol_inds.size() * size_t(ncols))
+        throw std::runtime_error{"Source and destination indices lengths must match"};
+    check(l3k_update_solution(mesh.ctx(), mesh.get(), d_x, ldx, d_xghost, ldxg, ncols, int(sol_inds.size()), sol_inds.data(),
+                              sol_man_inds.data(), d_fields, ldf, n_fields));
+}
+
 class MatrixFreeSystem
 {
 public:

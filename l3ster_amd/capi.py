@@ -159,6 +159,8 @@ SIGNATURES = {
     "l3k_values_at_nodes": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, C.c_double, C.c_int64, c_int64_p,
                                       c_uint8_p, c_int_p, _vp, _vp]),
     "l3k_average_values": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "l3k_update_solution": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, c_int_p, c_int_p, _vp, C.c_size_t,
+                                      C.c_int]),
     "l3k_jacobi_inverse": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, C.c_double, _vp]),
     "l3k_pcg_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(CgOpts), C.POINTER(CgResult)]),
     "l3k_cg_init": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),

@@ -242,6 +242,83 @@ int l3k_values_at_nodes(l3k_ctx* ctx, l3k_mesh* mesh, int residual_id, const voi
     L3K_HIP(hipStreamSynchronize(s)); // the staging buffers are released on return
     return 0;
 }
+// MatrixFreeSystem::updateSolution (algsys/MatrixFreeSystem.hpp:1231-1273): solution dofs -> SolutionManager fields
+__global__ void updateSolutionKernel(const double* __restrict__ x, size_t ldx, const double* __restrict__ xg, size_t ldxg, int64_t n_owned_nodes,
+                                     int64_t n_local_nodes, int dpn, int ncols, int n_inds, const int* __restrict__ sol_inds,
+                                     const int* __restrict__ dest, double* __restrict__ fields, size_t ldf)
+{
+    const int64_t total = n_local_nodes * n_inds * ncols;
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x)
+    {
+        // node fastest: neighbouring threads write neighbouring entries of one field (the SoA storage), reads at a stride of dpn
+        const int64_t node = t % n_local_nodes, ir = t / n_local_nodes;
+        const int     i = int(ir / ncols), r = int(ir - int64_t(i) * ncols);
+        const int64_t dof = node * dpn + sol_inds[i];
+        const double  v   = node < n_owned_nodes ? x[dof + ldx * r] : xg[(dof - n_owned_nodes * dpn) + ldxg * r];
+        fields[node + size_t(dest[i * ncols + r]) * ldf] = v;
+    }
+}
+
+int l3k_update_solution(l3k_ctx* ctx, l3k_mesh* mesh, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, int ncols,
+                        int n_inds, const int* sol_inds, const int* sol_man_inds, double* d_fields, size_t ldf, int n_fields)
+{
+    if (!ctx || !mesh || !d_x || !d_fields || !sol_inds || !sol_man_inds || ncols < 1 || n_inds < 0 || n_fields < 0)
+    {
+        setError("l3k_update_solution: bad argument");
+        return -1;
+    }
+    for (int i = 0; i < n_inds; ++i)
+        if (sol_inds[i] < 0 || sol_inds[i] >= mesh->dofs_per_node)
+        {
+            setError("Source index out of bounds"); // MatrixFreeSystem.hpp:1239-1240
+            return -1;
+        }
+    for (int i = 0; i < n_inds * ncols; ++i)
+        if (sol_man_inds[i] < 0 || sol_man_inds[i] >= n_fields)
+        {
+            setError("Destination index out of bounds"); // :1241-1242
+            return -1;
+        }
+    const int64_t n_local = mesh->n_owned_nodes + mesh->n_ghost_nodes;
+    if (mesh->n_ghost_nodes > 0 && !d_xghost)
+    {
+        setError("l3k_update_solution: the mesh has ghost nodes: pass the imported ghost rows (l3k_halo_import)");
+        return -1;
+    }
+    if (ldx < size_t(mesh->nOwnedDofs()) || ldf < size_t(n_local) || (d_xghost && ldxg < size_t(mesh->n_ghost_nodes * mesh->dofs_per_node)))
+    {
+        setError("l3k_update_solution: leading dimension too small");
+        return -1;
+    }
+    if (n_inds == 0 || n_local == 0)
+        return 0;
+    L3K_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int*        d_idx = nullptr; // [n_inds] source indices, then [n_inds * ncols] destination fields
+    const size_t n_idx = size_t(n_inds) * (1 + ncols);
+    std::vector< int > h(n_idx);
+    std::copy_n(sol_inds, n_inds, h.begin());
+    std::copy_n(sol_man_inds, size_t(n_inds) * ncols, h.begin() + n_inds);
+    L3K_HIP(hipMalloc(reinterpret_cast< void** >(&d_idx), n_idx * sizeof(int)));
+    if (hipMemcpyAsync(d_idx, h.data(), n_idx * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess)
+    {
+        (void)hipFree(d_idx);
+        setError("l3k_update_solution: copy of the index lists failed");
+        return -3;
+    }
+    hipLaunchKernelGGL(updateSolutionKernel, dim3(gridFor(n_local * n_inds * ncols)), dim3(256), 0, s, d_x, ldx, d_xghost, ldxg,
+                       mesh->n_owned_nodes, n_local, mesh->dofs_per_node, ncols, n_inds, d_idx, d_idx + n_inds, d_fields, ldf);
+    const hipError_t err = hipGetLastError();
+    const hipError_t sy  = hipStreamSynchronize(s); // (the staged index lists are released on return)
+    (void)hipFree(d_idx);
+    if (err != hipSuccess || sy != hipSuccess)
+    {
+        setError("l3k_update_solution: kernel failed: %s", hipGetErrorString(err != hipSuccess ? err : sy));
+        return -3;
+    }
+    return 0;
+}
+
 int l3k_average_values(l3k_ctx* ctx, const double* d_sum, const double* d_count, int64_t n, double* d_values)
 {
     if (!ctx || (n > 0 && (!d_sum || !d_count || !d_values)))

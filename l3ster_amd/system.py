@@ -439,6 +439,23 @@ def values_at_nodes(mesh, residual_id, dof_inds, values, fields=None, kernel_par
     return values
 
 
+def update_solution(mesh, X, sol_inds, fields, sol_man_inds, XG=None):
+    """MatrixFreeSystem::updateSolution (algsys/MatrixFreeSystem.hpp:1231-1273): the solution's per-node dofs `sol_inds` of every
+    column of X (ncols, n_owned_dofs) -- ghost rows from XG (ncols, n_ghost_dofs), the imported values -- into the fields
+    `sol_man_inds` (one per (index, column), index-major) of the SoA field storage `fields` (n_fields, n_local_nodes): what a
+    kernel's FieldAccess reads at the next assembly (time stepping, Newton iterations)."""
+    nc, ldx = MatrixFreeSystem._cols(X)
+    if fields.dim() != 2 or not fields.is_contiguous():
+        raise L3KError("fields must be a contiguous (n_fields, n_local_nodes) tensor")
+    if len(sol_man_inds) != len(sol_inds) * nc:
+        raise L3KError("Source and destination indices lengths must match")  # MatrixFreeSystem.hpp:1237-1238
+    si = (C.c_int * len(sol_inds))(*[int(i) for i in sol_inds])
+    di = (C.c_int * len(sol_man_inds))(*[int(i) for i in sol_man_inds])
+    check(capi.load().l3k_update_solution(mesh.ctx._h, mesh._h, _ptr(X), ldx, _ptr(XG), 0 if XG is None else XG.shape[1], nc,
+                                          len(sol_inds), si, di, _ptr(fields), fields.shape[1], fields.shape[0]))
+    return fields
+
+
 def norm_l2(mesh, residual_id, fields=None, kernel_params=None, asm_opts=(1, 0, 0), time=0.0, face_elem=None,
             face_side=None, group=None):
     """computeNormL2 (post/NormL2.hpp:31-62): sqrt of the integral of the squared residual with doubled quadrature

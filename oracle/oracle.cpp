@@ -1743,6 +1743,32 @@ int orc_diag_rhs_local(int kernel_id, int p, int nq, int R, const double* verts,
     return orc_diag_rhs_local_side(-1, kernel_id, p, nq, R, verts, node_fields, kparams, time, n_dir, dir_inds, dir_vals, diag, rhs);
 }
 
+// MatrixFreeSystem::updateSolution, algsys/MatrixFreeSystem.hpp:1231-1273: for every element, every local node, every (i, rhs):
+// sol_man(node, sol_man_inds[i * n_rhs + rhs]) = solution(dof(node, sol_inds[i]), rhs) -- the same value stored once per element that
+// holds the node (relaxed atomic stores in the reference).  x: [n_local_dofs][n_rhs] column-major over OWNED THEN GHOST rows (the
+// reference's BorderAccessor over the solution view and the import buffer); fields: SoA [n_fields][n_local_nodes]
+int orc_update_solution(const orc_mesh* m, const double* x, size_t ldx, int n_rhs, int n_inds, const int* sol_inds,
+                        const int* sol_man_inds, double* fields, int n_fields)
+{
+    for (int i = 0; i < n_inds; ++i)
+        if (sol_inds[i] < 0 || sol_inds[i] >= m->dofs_per_node)
+            return fail(-1, "Source index out of bounds"); // :1239-1240
+    for (int i = 0; i < n_inds * n_rhs; ++i)
+        if (sol_man_inds[i] < 0 || sol_man_inds[i] >= n_fields)
+            return fail(-1, "Destination index out of bounds"); // :1241-1242
+    const int N = ipow(m->p + 1, m->dim);
+    for (int64_t el = 0; el < m->n_elems; ++el)
+        for (int n = 0; n < N; ++n)
+        {
+            const int64_t node = m->elem_nodes[el * N + n];
+            for (int i = 0; i < n_inds; ++i)
+                for (int r = 0; r < n_rhs; ++r)
+                    fields[static_cast< size_t >(sol_man_inds[i * n_rhs + r]) * m->n_local_nodes + node] =
+                        x[node * m->dofs_per_node + sol_inds[i] + ldx * r];
+        }
+    return 0;
+}
+
 int orc_set_reference_z0(int on)
 {
     g_reference_z0 = on != 0;

@@ -148,6 +148,11 @@ int orc_mf_diag_rhs(const orc_mesh* m, int kernel_id, const double* kparams, dou
                     const double* dirichlet_vals, size_t ldg, double* diag, double* rhs, size_t ldr,
                     int64_t e_begin, int64_t e_end, int finalize, int64_t n_owned_dofs, int nthreads);
 
+/* MatrixFreeSystem::updateSolution (algsys/MatrixFreeSystem.hpp:1231-1273): x column-major [n_local_dofs][n_rhs] (owned then ghost
+ * rows), fields SoA [n_fields][n_local_nodes]; nodes no element holds keep their field values */
+int orc_update_solution(const orc_mesh* m, const double* x, size_t ldx, int n_rhs, int n_inds, const int* sol_inds,
+                        const int* sol_man_inds, double* fields, int n_fields);
+
 /* ---- boundary terms and post-processing ---------------------------------------------- */
 /* side < 0: domain.  Sides as mesh/ElementTraits.hpp:84-95: hex 0..5 = z-,z+,y-,y+,x-,x+; quad 0..3 = y-,y+,x-,x+ */
 /* full element basis at the quadrature of one side: vals[nq^(dim-1)][N], ders[.][dim][N], weights, points[.][dim].

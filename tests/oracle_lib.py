@@ -221,6 +221,18 @@ def apply_sumfact(kid, p, nq, verts, x, node_fields=None, kparams=None, time=0.0
     return y
 
 
+def update_solution(mesh, x, sol_inds, fields, sol_man_inds):
+    """MatrixFreeSystem::updateSolution: x [n_local_dofs, n_rhs] Fortran-ordered, fields [n_fields, n_local_nodes] (in place)."""
+    x = np.asfortranarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1, order="F")
+    assert fields.flags.c_contiguous and fields.shape[1] == mesh.n_local_nodes
+    si, di = np.ascontiguousarray(sol_inds, dtype=np.int32), np.ascontiguousarray(sol_man_inds, dtype=np.int32)
+    _chk(lib().orc_update_solution(C.byref(mesh.struct), _d(x), C.c_size_t(x.shape[0]), x.shape[1], len(si), si.ctypes.data_as(_ip),
+                                   di.ctypes.data_as(_ip), _d(fields), fields.shape[0]))
+    return fields
+
+
 def set_reference_z0(on):
     """mf_apply passes z = 0 to domain kernels as the reference's evalAtHexQPs does (SumFactorization.hpp:732); default off."""
     _chk(lib().orc_set_reference_z0(int(bool(on))))

@@ -214,3 +214,77 @@ def test_z0_mode_leaves_kernels_that_ignore_z_alone(ctx):
     mf.apply(X, Y1)
     torch.cuda.synchronize()
     assert torch.equal(Y0, Y1)
+
+
+def test_update_solution_vs_oracle(ctx):
+    """l3k_update_solution = MatrixFreeSystem::updateSolution (algsys/MatrixFreeSystem.hpp:1231-1273): dofs of the solution (two
+    columns, a subset of the per-node dofs, owned rows + imported ghost rows) into SolutionManager-style SoA fields; the reference's
+    index asserts come back as errors."""
+    p, dpn = 3, 5
+    part = system.CubePartition((4, 2, 2), p, parts=(2, 1, 1), rank=1, perturb=0.1)  # a rank with ghost nodes
+    assert part.n_ghost_nodes > 0
+    mesh = system.DeviceMesh(ctx, part, dpn)
+    rng = np.random.default_rng(8)
+    n_owned, n_ghost = part.n_owned_nodes * dpn, part.n_ghost_nodes * dpn
+    x = rng.uniform(-1, 1, (2, n_owned + n_ghost))
+    sol_inds, dest = [3, 0, 4], [5, 1, 0, 6, 2, 7]  # (index-major: (3, col 0) -> field 5, (3, col 1) -> field 1, (0, col 0) -> 0, ...)
+    f0 = rng.uniform(-1, 1, (9, part.n_local_nodes))
+    want = O.update_solution(oracle_mesh(part, p + 1, dpn, np.arange(dpn)), x.T, sol_inds, f0.copy(), dest)
+    got = system.update_solution(mesh, dev(x[:, :n_owned]), sol_inds, dev(f0), dest, XG=dev(x[:, n_owned:]))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(want[[3, 4, 8]], f0[[3, 4, 8]])  # fields that are no destination keep their values
+    with pytest.raises(system.L3KError, match="Source index out of bounds"):
+        system.update_solution(mesh, dev(x[:, :n_owned]), [5], dev(f0), [0, 1], XG=dev(x[:, n_owned:]))
+    with pytest.raises(system.L3KError, match="Destination index out of bounds"):
+        system.update_solution(mesh, dev(x[:, :n_owned]), [1], dev(f0), [0, 9], XG=dev(x[:, n_owned:]))
+    with pytest.raises(system.L3KError, match="lengths must match"):
+        system.update_solution(mesh, dev(x[:, :n_owned]), [1, 2], dev(f0), [0, 1, 2], XG=dev(x[:, n_owned:]))
+    with pytest.raises(system.L3KError, match="ghost"):
+        system.update_solution(mesh, dev(x[:, :n_owned]), [1], dev(f0), [0, 1])
+
+
+def test_bdf3_advection_time_stepping_end_to_end(ctx):
+    """The loop of examples/04-periodic-bc/source.cpp:97-140 in 3-D with the scalar advection kernel: per time step set the time,
+    compute diag + rhs with the three previous solutions as the kernel's fields (BDF3), solve with Jacobi-PCG, updateSolution rotates
+    the new solution into the field storage.  Device (fast scalar kernel, l3k_pcg_solve, l3k_update_solution) against the same loop
+    on the CPU with the oracle's operator, diag / rhs and updateSolution driving the torch-op CG: solutions agree after 3 steps."""
+    from l3ster_amd import solve
+    kid, p, U, dt = system.KERNEL_ADVECTION3D, 2, 1, 0.05
+    part = system.CubePartition((4, 3, 3), p, perturb=0.1)
+    mask = part.dirichlet_mask(U, sides=[4])  # inflow: the x- side
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), kid, [dt])
+    xyz = part.node_coords()
+    u0 = np.exp(-10.0 * ((xyz[:, 0] - 0.4) ** 2 + (xyz[:, 1] - 0.5) ** 2 + (xyz[:, 2] - 0.5) ** 2))
+    fields_d = dev(np.stack([u0, u0, u0]))  # history: u^n, u^{n-1}, u^{n-2}
+    fields_h = np.stack([u0, u0, u0])
+    mf.set_fields(fields_d)
+    n = part.n_local_nodes
+    on_inflow = mask.astype(bool)
+    for step in range(3):
+        t = (step + 1) * dt
+        g = np.zeros((1, n))  # homogeneous inflow value
+        # ---- device
+        mf.set_time(t)
+        diag, rhs = mf.diag_rhs(dev(g))
+        minv = solve.jacobi_inverse_native(ctx, diag)
+        x_d = fields_d[0].clone()
+        x_d[torch.as_tensor(on_inflow, device="cuda")] = 0.0
+        r_d = solve.pcg(mf, rhs[0], x_d, minv, tol=1e-11, residual_scaling="rhs")
+        # rotate the history: u^{n-1} -> u^{n-2}, u^n -> u^{n-1}, then the new solution into slot 0 through updateSolution
+        fields_d[2].copy_(fields_d[1])
+        fields_d[1].copy_(fields_d[0])
+        system.update_solution(mf.mesh, x_d[None, :], [0], fields_d, [0])
+        # ---- the same step on the CPU: oracle operator, diag / rhs, updateSolution; torch-op CG
+        om = oracle_mesh(part, p + 1, U, np.arange(U), mask, fields_h)
+        d_h, r_h = O.mf_diag_rhs(om, kid, 1, np.asfortranarray(g.T), kparams=[dt], time=t)
+        x_h = torch.as_tensor(fields_h[0].copy())
+        x_h[torch.as_tensor(on_inflow)] = 0.0
+        apply_h = lambda v, out: out.copy_(torch.as_tensor(O.mf_apply(om, kid, v.numpy().reshape(-1, 1), kparams=[dt], time=t)[:, 0]))
+        r_c = solve.cg(apply_h, torch.as_tensor(r_h[:, 0].copy()), x_h, torch.as_tensor(1.0 / d_h), tol=1e-11, residual_scaling="rhs")
+        assert abs(r_c.num_iters - r_d.num_iters) <= 3, (step, r_c.num_iters, r_d.num_iters)
+        fields_h[2], fields_h[1] = fields_h[1].copy(), fields_h[0].copy()
+        O.update_solution(oracle_mesh(part, p + 1, U, np.arange(U)), x_h.numpy(), [0], fields_h, [0])
+        err = np.abs(fields_d.cpu().numpy() - fields_h).max()
+        assert err < 1e-8, (step, err)
+    # the bump has moved: the solution changed, and stayed bounded
+    assert 0.01 < np.abs(fields_h[0] - u0).max() < 1.0

@@ -242,6 +242,22 @@ def test_reference_z0_is_what_the_sumfact_path_passes(golden):
     assert np.linalg.norm(O.mf_apply(om, kid, g["x"], kparams=g["kparams"], time=t) - y_true) < 1e-13 * np.linalg.norm(g["y"])
 
 
+def test_update_solution_restatement():
+    """MatrixFreeSystem::updateSolution (algsys/MatrixFreeSystem.hpp:1231-1273): dofs sol_inds of column r -> field
+    sol_man_inds[i * n_rhs + r]; the reference's index asserts."""
+    from helpers import SingleElementMesh, oracle_mesh
+    m = oracle_mesh(SingleElementMesh(2, HEX), 3, 3, np.arange(3))
+    x = np.arange(27 * 3 * 2, dtype=float).reshape(2, 81).T
+    f = np.full((5, 27), -1.0)
+    O.update_solution(m, x, [2, 0], f, [3, 1, 0, 2])
+    assert np.array_equal(f[3], x[2::3, 0]) and np.array_equal(f[1], x[2::3, 1])
+    assert np.array_equal(f[0], x[0::3, 0]) and np.array_equal(f[2], x[0::3, 1]) and np.all(f[4] == -1.0)
+    with pytest.raises(RuntimeError, match="Source index out of bounds"):
+        O.update_solution(m, x, [3], f, [0, 1])
+    with pytest.raises(RuntimeError, match="Destination index out of bounds"):
+        O.update_solution(m, x, [1], f, [0, 5])
+
+
 def test_degenerate_element_is_reported():
     """algsys/AssembleLocalSystem.hpp:249, EvaluateLocalOperator.hpp:229: detJ <= 0 -> error"""
     bad = HEX.copy()
