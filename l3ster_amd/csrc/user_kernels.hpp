@@ -276,6 +276,27 @@ struct Robin3D
     }
 };
 
+// Robin condition with coefficients read from the point and the time (synthetic): q . n + h(x, t) T = h(x, t) T_inf(x)
+struct RobinPoint3D
+{
+    static constexpr KernelParams params{.dimension = 3, .n_equations = 1, .n_unknowns = 4};
+    double                        h0 = 1., t0 = 0.;
+
+    template < typename In, typename Out >
+    L3K_HD void operator()(const In& in, Out& out) const
+    {
+        const auto& [vals, ders, point, normal] = in;
+        const double h         = h0 * (1. + .5 * sin(point.space.x() - point.space.y() + point.time));
+        auto& [operators, rhs] = out;
+        auto& [A0, A1, A2, A3] = operators;
+        A0(0, 0) = h;
+        A0(0, 1) = normal[0];
+        A0(0, 2) = normal[1];
+        A0(0, 3) = normal[2];
+        rhs[0]   = h * t0 * (1. + point.space.z());
+    }
+};
+
 // Boundary kernel with derivative operators (synthetic): n . grad T + c d(q_x)/dx + h T = g -- fills A1..A3, so the side
 // kernel's normal-derivative path (every node of the element takes part) is exercised
 struct NormalFlux3D
@@ -370,7 +391,8 @@ struct Unit3D
 #define L3K_FOR_EACH_BOUNDARY_KERNEL(X)                                                                                \
     X(6, ::l3k::kernels::Adiabatic3D, "adiabatic3d")                                                                   \
     X(7, ::l3k::kernels::Robin3D, "robin3d")                                                                           \
-    X(9, ::l3k::kernels::NormalFlux3D, "normalflux3d")
+    X(9, ::l3k::kernels::NormalFlux3D, "normalflux3d")                                                                 \
+    X(14, ::l3k::kernels::RobinPoint3D, "robinpoint3d")
 
 // residual kernels (own id space; 1 and 3 are the 2-D kernels of the CPU oracle)
 #define L3K_FOR_EACH_RESIDUAL_KERNEL(X)                                                                                \
@@ -423,7 +445,11 @@ struct Unit3D
     X(::l3k::kernels::NormalFlux3D, 2, 3, 1)                                                                           \
     X(::l3k::kernels::NormalFlux3D, 2, 3, 2)                                                                           \
     X(::l3k::kernels::NormalFlux3D, 3, 7, 1)                                                                           \
-    X(::l3k::kernels::NormalFlux3D, 4, 5, 1)
+    X(::l3k::kernels::NormalFlux3D, 4, 5, 1)                                                                           \
+    X(::l3k::kernels::RobinPoint3D, 2, 3, 1)                                                                           \
+    X(::l3k::kernels::RobinPoint3D, 2, 3, 2)                                                                           \
+    X(::l3k::kernels::RobinPoint3D, 3, 7, 1)                                                                           \
+    X(::l3k::kernels::RobinPoint3D, 4, 5, 1)
 
 // (functor, order p, nq); computeNormL2 doubles the quadrature orders: nq = 2p+1 for the default options
 #define L3K_FOR_EACH_RESIDUAL_INSTANCE(X)                                                                              \

@@ -27,6 +27,7 @@ KERNEL_DIVCURL3D = 12  # div-curl system, U = 3, E = 4
 KERNEL_ADIABATIC3D = 6  # boundary equation kernels
 KERNEL_ROBIN3D = 7
 KERNEL_NORMALFLUX3D = 9  # boundary kernel with derivative operators (A1..A3)
+KERNEL_ROBINPOINT3D = 14  # boundary kernel whose coefficients read point.space and point.time
 RESIDUAL_DIFFUSION3D_ERROR = 0
 RESIDUAL_LINEAR3D_ERROR = 2
 RESIDUAL_UNIT3D = 4

@@ -351,6 +351,20 @@ void kNormalFlux3D(const KIn& in, KOut& o)
     o.f(0)        = g;
 }
 
+// Robin condition whose coefficients read the point and the time (synthetic: a boundary kernel as the reference's examples write
+// them -- examples/02, 06 evaluate wall data at point.space): q . n + h(x, t) T = h(x, t) T_inf(x), h = h0 (1 + 0.5 sin(x - y + t)),
+// T_inf = t0 (1 + z).  kp = {h0, t0}
+void kRobinPoint3D(const KIn& in, KOut& o)
+{
+    const double h0 = in.kp ? in.kp[0] : 1., t0 = in.kp ? in.kp[1] : 0.;
+    const double h  = h0 * (1. + .5 * std::sin(in.x - in.y + in.t));
+    o.op(0, 0, 0)   = h;
+    o.op(0, 0, 1)   = in.normal[0];
+    o.op(0, 0, 2)   = in.normal[1];
+    o.op(0, 0, 3)   = in.normal[2];
+    o.f(0)          = h * t0 * (1. + in.z);
+}
+
 // Mass-type kernel (A0 = I, rhs = (1, 2)): twin of l3k::kernels::Mass3D, the known answer for w * detJ in the domain path
 void kMass3D(const KIn&, KOut& o)
 {
@@ -499,7 +513,8 @@ const KernelEntry* getKernel(int id)
                                         {{3, 7, 4, 0}, kDiffusion3DPoint},
                                         {{3, 1, 1, 3}, kAdvection3D},
                                         {{3, 4, 3, 0}, kDivCurl3D},
-                                        {{3, 8, 7, 7}, kNS3D}};
+                                        {{3, 8, 7, 7}, kNS3D},
+                                        {{3, 1, 4, 0}, kRobinPoint3D, true}};
     if (id < 0 || id >= static_cast< int >(sizeof(table) / sizeof(table[0])))
         return nullptr;
     return &table[id];

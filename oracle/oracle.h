@@ -44,7 +44,8 @@ enum
     ORC_KERNEL_DIFFUSION3D_POINT = 10, /* Diffusion3D with k, A0 and s functions of (x, y, z, t); kp = {k0, s0}    */
     ORC_KERNEL_ADVECTION3D       = 11, /* scalar BDF3 advection, U = E = 1, F = 3, velocity from the point; kp = {dt} */
     ORC_KERNEL_DIVCURL3D         = 12, /* div-curl system, U = 3, E = 4; kp = {f}                                   */
-    ORC_KERNEL_NS3D              = 13  /* benchmarks/Kernels.hpp:3-65: U = 7, E = 8, F = 7                          */
+    ORC_KERNEL_NS3D              = 13, /* benchmarks/Kernels.hpp:3-65: U = 7, E = 8, F = 7                          */
+    ORC_KERNEL_ROBINPOINT3D      = 14  /* boundary kernel reading point and time: q.n + h(x,t) T = h(x,t) T_inf(x); kp = {h0, t0} */
 };
 /* residual kernels for integrals / L2 norms (fields are the kernel's n_fields inputs) */
 enum

@@ -309,6 +309,7 @@ KERNEL_ADIABATIC2D = 5
 KERNEL_ADIABATIC3D = 6
 KERNEL_ROBIN3D = 7
 KERNEL_NORMALFLUX3D = 9
+KERNEL_ROBINPOINT3D = 14  # boundary kernel whose coefficients read point.space and point.time
 RESIDUAL_DIFFUSION3D_ERROR = 0
 RESIDUAL_LINEAR2D_ERROR = 1
 RESIDUAL_LINEAR3D_ERROR = 2

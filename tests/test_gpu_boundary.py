@@ -52,17 +52,21 @@ def _setup(S, ctx, ne, p, perturb=0.15, dir_sides=(0, 5)):
     return part, mesh, mask, U
 
 
-@pytest.mark.parametrize("kernel", ["robin", "normalflux"])
+@pytest.mark.parametrize("kernel", ["robin", "normalflux", "robinpoint"])
 @pytest.mark.parametrize("p,opts,R", [(2, (1, 0, 0), 1), (2, (1, 0, 0), 2), (4, (1, 0, 0), 1), (3, (2, 0, 0), 1)])
 def test_boundary_term_vs_oracle(S, ctx, p, opts, R, kernel):
     """`normalflux` fills A1..A3 (n . grad T + c dq_x/dx + h T = g): the side kernel's derivative path, in which every node
     of the element takes part (algsys/EvaluateLocalOperator.hpp:238-274), against the oracle's dense side matrices."""
     part, mesh, mask, U = _setup(S, ctx, 3, p)
     nq = S.n_qps1d(p, *opts[:2])
-    kp = [2.0, 0.7] if kernel == "robin" else [2.0, 0.7, 0.3]
-    dev_kid, orc_kid = (S.KERNEL_ROBIN3D, O.KERNEL_ROBIN3D) if kernel == "robin" else (S.KERNEL_NORMALFLUX3D, O.KERNEL_NORMALFLUX3D)
+    kp = [2.0, 0.7, 0.3] if kernel == "normalflux" else [2.0, 0.7]
+    dev_kid, orc_kid = {"robin": (S.KERNEL_ROBIN3D, O.KERNEL_ROBIN3D), "normalflux": (S.KERNEL_NORMALFLUX3D, O.KERNEL_NORMALFLUX3D),
+                        "robinpoint": (S.KERNEL_ROBINPOINT3D, O.KERNEL_ROBINPOINT3D)}[kernel]
+    # (`robinpoint`: the coefficients read in.point.space and in.point.time -- l3k_bnd_set_time -- as the reference's wall kernels do)
+    t = 0.65 if kernel == "robinpoint" else 0.0
     fe, fs = part.boundary_sides([1, 3, 4, 2] if kernel == "robin" else [0, 1, 2, 3, 4, 5])
     term = S.BoundaryTerm(mesh, dev_kid, fe, fs, kernel_params=kp, asm_opts=opts, n_rhs=R)
+    term.set_time(t)
     om = helpers.oracle_mesh(part, nq, U, [0, 1, 2, 3], dirichlet=mask)
     rng = np.random.default_rng(p)
     x = rng.standard_normal((R, part.n_local_nodes * U))
@@ -70,7 +74,7 @@ def test_boundary_term_vs_oracle(S, ctx, p, opts, R, kernel):
     Y = dev(y0)
     term.apply(dev(x), Y, alpha=1.5)
     want = np.asfortranarray(y0.T.copy())
-    O.bnd_apply(om, orc_kid, fe, fs, np.asfortranarray(x.T), want, alpha=1.5, kparams=kp)
+    O.bnd_apply(om, orc_kid, fe, fs, np.asfortranarray(x.T), want, alpha=1.5, kparams=kp, time=t)
     assert helpers.rel_err(Y.cpu().numpy().T, want) < 1e-12
     # diag / rhs with Dirichlet lifting
     g = np.where(mask[None, :] != 0, rng.standard_normal((R, mask.size)), 0.0)
@@ -79,9 +83,14 @@ def test_boundary_term_vs_oracle(S, ctx, p, opts, R, kernel):
     term.diag_rhs(diag, rhs, dirichlet_vals=dev(g))
     wd = np.zeros(mask.size)
     wr = np.zeros((mask.size, R), order="F")
-    O.bnd_diag_rhs(om, orc_kid, fe, fs, wd, wr, dirichlet_vals=np.asfortranarray(g.T), kparams=kp)
+    O.bnd_diag_rhs(om, orc_kid, fe, fs, wd, wr, dirichlet_vals=np.asfortranarray(g.T), kparams=kp, time=t)
     assert helpers.rel_err(diag.cpu().numpy(), wd) < 1e-12
     assert helpers.rel_err(rhs.cpu().numpy().T, wr) < 1e-11
+    if kernel == "robinpoint":  # the time really enters: another time, another term
+        Y2 = dev(y0)
+        term.set_time(0.0)
+        term.apply(dev(x), Y2, alpha=1.5)
+        assert helpers.rel_err(Y2.cpu().numpy().T, want) > 1e-4
 
 
 def test_attached_boundary_in_apply(S, ctx):
