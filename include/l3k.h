@@ -341,7 +341,9 @@ int l3k_cg_update_px(l3k_ctx* ctx, double* d_p, double* d_x, const double* d_z, 
  * assembleLocalSystem for a batch of elements, algsys/AssembleLocalSystem.hpp:234-256: K_e row-major [Nd][Nd],
  * F_e column-major [Nd][n_rhs] per element, elements [first, first+count).  d_K may be NULL (then only the checksum
  * below is produced); d_checksum[count] receives sum_ij K_e[i][j]*(1 + ((i*31 + j*17) % 7)) (streaming mode,
- * SURVEY.md §0 D6). */
+ * SURVEY.md §0 D6).  K_e is symmetric bit for bit, like the reference's selfadjointView copy (:176-182).  From order 4 the stored
+ * matrices are formed in the tiled layout of l3k_local_assemble_tiled and turned by a transposition kernel on a second stream
+ * (the function returns when the matrices are complete); l3k_tuning selects the other routes (direct store, dense product). */
 int l3k_local_assemble(l3k_mf* mf, int64_t first, int64_t count, double* d_K, double* d_F, double* d_checksum);
 
 /* scatterLocalSystem for a batch, algsys/ScatterLocalSystem.hpp:24-54 (called per element by assembleGlobalSystem,
