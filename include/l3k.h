@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* 101 (round 4): l3k_cg_update_xr / _update_p replaced by l3k_cg_update_z / _update_px (the iteration keeps z = M^-1 r; d_r holds z),
- * new: l3k_ctx_set_reference_z0, l3k_ctx_get/set_tuning, l3k_mf_route, l3k_update_solution */
+ * new: l3k_ctx_set_reference_z0, l3k_ctx_get/set_tuning, l3k_mf_route, l3k_update_solution, l3k_pcg_solve_cols */
 #define L3K_VERSION 101
 
 typedef struct l3k_ctx      l3k_ctx;
@@ -315,6 +315,10 @@ typedef struct
 int l3k_jacobi_inverse(l3k_ctx* ctx, const double* d_diag, int64_t n, double damping, double threshold, double* d_minv);
 int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_minv, const l3k_cg_opts* opts,
                   l3k_cg_result* result);
+/* ... for the ncols columns of a multivector (column c at + c * ld), one after the other as Belos "Block CG" with block size 1
+ * does for the reference's n_rhs right-hand sides; results[ncols] */
+int l3k_pcg_solve_cols(l3k_mf* mf, const double* d_b, size_t ldb, double* d_x, size_t ldx, int ncols, const double* d_minv,
+                       const l3k_cg_opts* opts, l3k_cg_result* results);
 /* The pieces of the iteration for hosts that reduce the scalars across ranks themselves (d_s: device block, 0 <r,z> old, 1 <p,Ap>,
  * 2 <r,z> new, 3 <r,r>).  The iteration keeps the preconditioned residual z = M^-1 r instead of r (9 instead of 11 vector passes):
  *   l3k_cg_init:      d_z holds A x0 on entry; z = minv (b - A x0), p = z, s[2] = <r,z>, s[3] = <r,r> (this rank's share)

@@ -163,6 +163,7 @@ SIGNATURES = {
                                       C.c_int]),
     "l3k_jacobi_inverse": (C.c_int, [_vp, _vp, C.c_int64, C.c_double, C.c_double, _vp]),
     "l3k_pcg_solve": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(CgOpts), C.POINTER(CgResult)]),
+    "l3k_pcg_solve_cols": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, C.POINTER(CgOpts), C.POINTER(CgResult)]),
     "l3k_cg_init": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "l3k_cg_dot_pap": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "l3k_mf_apply_energy": (C.c_int, [_vp, _vp, _vp, _vp]),

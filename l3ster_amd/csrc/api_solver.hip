@@ -288,4 +288,25 @@ int l3k_pcg_solve(l3k_mf* mf, const double* d_b, double* d_x, const double* d_mi
     result->converged    = res <= o.tol;
     return 0;
 }
+// the same for a multivector of right-hand sides (the reference's systems carry n_rhs columns: Belos "Block CG" with block size 1
+// iterates them one after the other, solve/BelosSolvers.hpp:116-122): column c of d_b / d_x at + c * ld; results[ncols]
+int l3k_pcg_solve_cols(l3k_mf* mf, const double* d_b, size_t ldb, double* d_x, size_t ldx, int ncols, const double* d_minv,
+                       const l3k_cg_opts* opts, l3k_cg_result* results)
+{
+    if (!mf || !d_b || !d_x || !results || ncols < 1)
+    {
+        setError("l3k_pcg_solve_cols: bad argument");
+        return -1;
+    }
+    const size_t n = size_t(mf->mesh->nOwnedDofs());
+    if (ncols > 1 && (ldb < n || ldx < n))
+    {
+        setError("l3k_pcg_solve_cols: leading dimension smaller than the number of owned dofs");
+        return -1;
+    }
+    for (int c = 0; c < ncols; ++c)
+        if (int rc = l3k_pcg_solve(mf, d_b + ldb * c, d_x + ldx * c, d_minv, opts, results + c))
+            return rc;
+    return 0;
+}
 } // extern "C"

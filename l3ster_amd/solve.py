@@ -86,6 +86,18 @@ def pcg(system, b, x, minv=None, tol=1e-6, max_iters=10_000, residual_scaling="n
     import ctypes as C
     from . import capi
     opts = capi.CgOpts(float(tol), int(max_iters), _SCALING[residual_scaling], int(check_every))
+    if b.dim() == 2:  # a multivector (ncols, ld) of right-hand sides: the columns one after the other (l3k_pcg_solve_cols)
+        nc = b.shape[0]
+        if x.shape != b.shape or b.stride(1) != 1 or x.stride(1) != 1:
+            raise capi.L3KError("b and x must be (ncols, ld) tensors of one shape with unit stride along rows")
+        res_c = (capi.CgResult * nc)()
+        capi.check(capi.load().l3k_pcg_solve_cols(system._h, C.c_void_p(b.data_ptr()), b.stride(0) if nc > 1 else b.shape[1],
+                                                  C.c_void_p(x.data_ptr()), x.stride(0) if nc > 1 else x.shape[1], nc,
+                                                  C.c_void_p(0 if minv is None else minv.data_ptr()), C.byref(opts), res_c))
+        out = [IterSolveResult(r.achieved_tol, r.iterations, bool(r.converged)) for r in res_c]
+        if throw_on_fail and not all(r.converged for r in out):
+            raise RuntimeError("Solver failed to converge")  # solve/BelosSolvers.hpp:103
+        return out
     res = capi.CgResult()
     capi.check(capi.load().l3k_pcg_solve(system._h, C.c_void_p(b.data_ptr()), C.c_void_p(x.data_ptr()),
                                          C.c_void_p(0 if minv is None else minv.data_ptr()), C.byref(opts), C.byref(res)))

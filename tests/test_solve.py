@@ -125,6 +125,42 @@ def test_native_pcg_matches_torch_pcg():
 
 
 @pytest.mark.gpu
+def test_k1_three_right_hand_sides_through_the_device_solver():
+    """K1 at mesh level (tests/LocalAssemblyTests.cpp:3-43: R = D right-hand sides, Dirichlet on unknown 0 at the boundary nodes with
+    phi = x_d, the diffusion kernel with zero source -> column d of the solution is T = x_d, q = e_d): value_order 2, three columns
+    through l3k_mf_diag_rhs and l3k_pcg_solve_cols (the reference hands its n_rhs-column multivector to Belos Block CG)."""
+    import torch
+    from l3ster_amd import solve, system
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    p, U, R = 3, 4, 3
+    part = system.CubePartition(3, p, perturb=0.15)
+    mask = part.dirichlet_mask(U)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), system.KERNEL_DIFFUSION3D, [1.0, 0.0], asm_opts=(2, 0, 0), n_rhs=R)
+    xyz = part.node_coords()
+    g = np.zeros((R, part.n_local_nodes, U))
+    for d in range(R):
+        g[d, :, 0] = xyz[:, d]
+    g = g.reshape(R, -1) * mask[None, :]
+    diag, rhs = mf.diag_rhs(torch.as_tensor(g, device="cuda"))
+    minv = solve.jacobi_inverse_native(ctx, diag)
+    x = torch.zeros_like(rhs)
+    results = solve.pcg(mf, rhs, x, minv, tol=1e-12, residual_scaling="rhs")
+    assert len(results) == R and all(r.converged for r in results)
+    sol = x.cpu().numpy().reshape(R, -1, U)
+    for d in range(R):
+        want = np.zeros((part.n_local_nodes, U))
+        want[:, 0] = xyz[:, d]
+        want[:, 1 + d] = 1.0
+        assert np.abs(sol[d] - want).max() < 1e-6, d  # the reference's bar (rel 1e-6)
+        assert np.abs(sol[d] - want).max() < 1e-8, d
+    # one column through the single-column entry point gives the same bits as that column of the multivector solve
+    x0 = torch.zeros_like(rhs[0])
+    solve.pcg(mf, rhs[0].contiguous(), x0, minv, tol=1e-12, residual_scaling="rhs")
+    assert (x0 - x[0]).abs().max().item() < 1e-10
+
+
+@pytest.mark.gpu
 def test_pcg_with_zero_preconditioner_entries():
     """the iteration keeps z = M^-1 r, and r = z / minv was 0 / 0 = NaN on rows where the caller's preconditioner is
     zero (the common way to freeze constrained dofs; l3k_jacobi_inverse with damping 0).  Such rows are frozen now: x keeps its
