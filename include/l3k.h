@@ -133,10 +133,12 @@ typedef struct
     int     assemble_two_launches; /* stored row-major LocalAssembly as two launches (diagonal / off-diagonal blocks); 0        */
     int     scatter_per_entry;     /* l3k_assembled_scatter: one wave per row with a search per entry (round-2 kernel); 0       */
     int     assemble_direct_store; /* stored row-major LocalAssembly written by the assembly kernel itself (8-byte stores at a
-                                      32-byte stride, 3.9 x write traffic) instead of tiled + transposition kernel; 0           */
+                                      32-byte stride, 3.9 x write traffic) instead of x-major tiled layout + mirroring
+                                      transposition kernel; 0                                                                   */
     int     assemble_sub_batch;    /* stored row-major LocalAssembly: elements per pipelined sub-batch, 0 = chosen by size; 0      */
-    int     assemble_no_symmetrise; /* stored row-major LocalAssembly without the pass that mirrors the lower triangle: K_e then
-                                      symmetric to rounding (1e-13) instead of bit for bit like the reference's; 0              */
+    int     assemble_no_symmetrise; /* stored row-major LocalAssembly through the plain tiled layout and the plain transposition
+                                      (both triangles formed, each in its own summation order): K_e symmetric to rounding
+                                      (1e-13) instead of bit for bit like the reference's -- the cross-check of the default; 0  */
 } l3k_tuning;
 int l3k_ctx_get_tuning(const l3k_ctx* ctx, l3k_tuning* out);
 int l3k_ctx_set_tuning(l3k_ctx* ctx, const l3k_tuning* in);

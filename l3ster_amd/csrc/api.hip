@@ -1457,6 +1457,10 @@ static int assembleRowMajorViaTiled(l3k_mf* mf, const l3k::dev::Instance* inst, 
     }
     hipStream_t sa   = mf->ctx->stream;
     const void* blob = mf->blob.empty() ? nullptr : mf->blob.data();
+    // bitwise symmetric matrices, as the reference returns them: the x-major tiled layout and the one-pass mirroring transposition
+    // (api_assembled.hip).  l3k_tuning::assemble_no_symmetrise: the plain tiled layout and the plain transposition (K[i][j] and
+    // K[j][i] then differ by rounding) -- the cross-check of the former
+    const bool sym = !mf->ctx->tune.assemble_no_symmetrise;
     for (int k = 0; k < 2; ++k) // (the flags of degenerate elements: the trailing double of each coefficient workspace)
         L3K_HIP(hipMemsetAsync(g.buf[k] + kd + inst->assemble_ws_doubles * size_t(nb), 0, sizeof(double), sa));
     int64_t done  = 0;
@@ -1474,17 +1478,15 @@ static int assembleRowMajorViaTiled(l3k_mf* mf, const l3k::dev::Instance* inst, 
         a.elem_count     = n;
         a.elem_begin_out = 0;
         a.K              = g.buf[k];
-        a.K_tiled        = 1;
+        a.K_tiled        = sym ? 2 : 1;
         a.workspace      = g.buf[k] + kd + size_t(nb - n) * inst->assemble_ws_doubles; // (the flag keeps one position per buffer)
         if (int rc = inst->assemble(a, blob, sa))
             return rc;
         L3K_HIP(hipEventRecord(g.formed[k], sa));
         L3K_HIP(hipStreamWaitEvent(g.second, g.formed[k], 0));
-        if (int rc = launchTiledToRowMajor(U, N1, n, g.buf[k], d_K + size_t(done) * mat, g.second))
+        if (int rc = sym ? launchTiledXToRowMajorSym(U, N1, n, g.buf[k], d_K + size_t(done) * mat, g.second)
+                         : launchTiledToRowMajor(U, N1, n, g.buf[k], d_K + size_t(done) * mat, g.second))
             return rc;
-        if (!mf->ctx->tune.assemble_no_symmetrise) // (bitwise symmetric matrices, as the reference returns them)
-            if (int rc = launchSymmetrise(Nd, n, d_K + size_t(done) * mat, g.second))
-                return rc;
         L3K_HIP(hipEventRecord(g.consumed[k], g.second));
         done += n;
     }

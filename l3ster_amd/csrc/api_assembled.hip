@@ -318,59 +318,129 @@ int launchTiledToRowMajorU(int N1, int64_t blocks, const double* Kt, double* K, 
     }
     return 0;
 }
-// K_e <- its lower triangle mirrored (the reference's getSystem: selfadjointView copy, AssembleLocalSystem.hpp:176-182): the tiled
-// kernel forms K[i][j] and K[j][i] in two different summation orders (equal to rounding); the reference's matrix is symmetric
-// bit for bit.  One workgroup per pair of 64 x 64 tiles (I > J): tile (I, J) read with coalesced rows, turned in LDS, written to
-// (J, I) with coalesced rows; diagonal tiles mirror themselves.
-__global__ __launch_bounds__(256) void symmetriseKernel(double* __restrict__ K, int Nd)
+// The x-major tiled layout -> the reference's row-major K_e, bitwise symmetric, in ONE pass over the matrix
+// (AssembleLocalSystem.hpp:168-182: getSystem returns the lower triangle mirrored).  The assembly kernels form K[i][j] and K[j][i]
+// in two summation orders (equal to rounding); only the lower triangle is read here and every entry is written twice, to (i, j)
+// and to (j, i).  The layout that makes this a streaming kernel is the tiled one with the roles of x and z exchanged
+// (ElemArgs::K_tiled == 2: the coefficient kernel hands the quadrature points and the reference derivatives over with x and z
+// swapped, the assembly kernel is the same code): [u][u'][bz'][bx][bz][by][by'][bx'] -- a run of n^2 doubles is then the n^2 column
+// nodes of one z'-slab in the order of the row-major matrix, for one u'.  One workgroup per (element, x-line l = (by, bz) of row
+// nodes: n U adjacent rows); per z'-slab it reads the runs of the slab's column lines l' <= l (whole runs: every byte of the lower
+// triangle once), keeps the n U x n^2 U block in LDS and writes
+//   * the block itself: n U row segments of n^2 U contiguous doubles (1 568 bytes at order 6),
+//   * its mirror image: n^2 U row segments of n U contiguous doubles (224 bytes); the line block l' == l mirrors itself.
+// Segments start on 32-byte boundaries; the half lines at their ends are completed by the neighbouring x-line's workgroup, which
+// runs on the same XCD (workgroups of one element share an index modulo 8) at about the same time.
+template < int U, int N1 >
+__global__ __launch_bounds__(256) void tiledXToRowMajorSymKernel(const double* __restrict__ Kt, double* __restrict__ K, int64_t count)
 {
-    constexpr int    T = 64;
-    __shared__ double tile[T][T + 1];
-    const int nt    = (Nd + T - 1) / T, npairs = nt * (nt + 1) / 2;
-    const int64_t e = blockIdx.x / npairs;
-    int       rem   = int(blockIdx.x - e * npairs), ti = 0; // lower-triangular tile index -> (ti, tj <= ti)
-    while (rem > ti)
+    constexpr int N2 = N1 * N1, NN = N2 * N1, Nd = NN * U, R = N1 * U, CW = N2 * U, LD = CW + 1;
+    extern __shared__ double tile[]; // [R][LD]: row (bx, u) of the x-line, column (by', bx', u') of the slab
+    const int64_t chunk = blockIdx.x / (8 * N2);
+    const int     w     = int(blockIdx.x - chunk * (8 * N2));
+    const int64_t e     = chunk * 8 + (w & 7);
+    if (e >= count)
+        return;
+    const int     l  = N2 - 1 - (w >> 3); // (the lines with most columns first)
+    const int     by = l % N1, bz = l / N1;
+    const int     tid = threadIdx.x;
+    const double* Te  = Kt + e * int64_t(Nd) * Nd;
+    double*       Ke  = K + e * int64_t(Nd) * Nd;
+    for (int bzp = 0; bzp <= bz; ++bzp)
     {
-        rem -= ti + 1;
-        ++ti;
-    }
-    const int tj = rem;
-    double*   Ke = K + e * int64_t(Nd) * Nd;
-    const int c = threadIdx.x & (T - 1), r0 = threadIdx.x >> 6; // 4 rows per pass
-    {
-        double v[T / 4]; // (all sixteen loads of a thread in flight before the first LDS store)
-#pragma unroll
-        for (int k = 0; k < T / 4; ++k)
+        const int run   = bzp < bz ? N2 : (by + 1) * N1; // column nodes (by', bx') of the slab on lines l' <= l
+        const int total = U * U * N1 * run;
+        constexpr int NB = 8; // independent loads in flight per thread
+        for (int t0 = tid; t0 < total; t0 += 256 * NB)
         {
-            const int gi = ti * T + r0 + 4 * k, gj = tj * T + c;
-            v[k]         = gi < Nd && gj < Nd ? Ke[int64_t(gi) * Nd + gj] : 0.;
-        }
+            double v[NB];
+            int    dst[NB];
 #pragma unroll
-        for (int k = 0; k < T / 4; ++k)
-            tile[r0 + 4 * k][c] = v[k];
-    }
-    __syncthreads();
-    for (int r = r0; r < T; r += 4)
-    {
-        const int gi = tj * T + r, gj = ti * T + c; // entry (gi, gj) of the mirrored tile <- tile[c][r] = K[gj][gi]
-        if (gi < Nd && gj < Nd && gj > gi)
-            Ke[int64_t(gi) * Nd + gj] = tile[c][r];
+            for (int k = 0; k < NB; ++k)
+            {
+                const int t = t0 + 256 * k;
+                if (t < total)
+                {
+                    const int j = t % run, r = t / run, bx = r % N1, uu = r / N1, u = uu / U, up = uu - u * U;
+                    v[k]   = Te[((((int64_t(uu) * N1 + bzp) * N1 + bx) * N1 + bz) * N1 + by) * N2 + j];
+                    dst[k] = (bx * U + u) * LD + j * U + up;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (t0 + 256 * k < total)
+                    tile[dst[k]] = v[k];
+        }
+        __syncthreads();
+        const int ncol = run * U;
+        for (int o = tid; o < R * ncol; o += 256)
+        {
+            const int r = o / ncol, c = o - r * ncol;
+            double    v = tile[r * LD + c];
+            if (bzp == bz)
+            {
+                const int cc = c - by * R; // position within the line block l' == l: its upper part comes from the mirror position
+                if (cc > r)
+                    v = tile[cc * LD + by * R + r];
+            }
+            Ke[(int64_t(l) * R + r) * Nd + bzp * CW + c] = v;
+        }
+        const int nm = (bzp < bz ? N2 : by * N1) * U; // rows of the mirror image (the line block l' == l has none)
+        for (int o = tid; o < nm * R; o += 256)
+        {
+            const int rr = o / R, r = o - rr * R;
+            Ke[(int64_t(bzp) * CW + rr) * Nd + l * R + r] = tile[r * LD + rr];
+        }
+        __syncthreads();
     }
 }
-// `count` element matrices: tiled (d_Kt) -> row-major (d_K), on stream s
-int launchSymmetrise(int Nd, int64_t count, double* d_K, hipStream_t s)
+template < int U, int N1 >
+int launchTiledXOne(int64_t count, const double* Kt, double* K, hipStream_t s)
 {
-    const int     nt     = (Nd + 63) / 64;
-    const int64_t blocks = count * (int64_t(nt) * (nt + 1) / 2);
-    if (blocks > int64_t(0x7fffffff))
+    constexpr size_t lds    = sizeof(double) * size_t(N1) * U * (N1 * N1 * U + 1);
+    if constexpr (lds > 64 * 1024) // (order 7 with 4 unknowns; an attribute of the function on the CURRENT device: set per launch)
+        if (hipFuncSetAttribute(reinterpret_cast< const void* >(&tiledXToRowMajorSymKernel< U, N1 >), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+            return 1;
+    const int64_t blocks = ((count + 7) / 8) * 8 * N1 * N1;
+    hipLaunchKernelGGL((tiledXToRowMajorSymKernel< U, N1 >), dim3(unsigned(blocks)), dim3(256), lds, s, Kt, K, count);
+    return 0;
+}
+template < int U >
+int launchTiledXU(int N1, int64_t count, const double* Kt, double* K, hipStream_t s)
+{
+    switch (N1)
     {
-        setError("symmetrise: batch too large");
+    case 2: return launchTiledXOne< U, 2 >(count, Kt, K, s);
+    case 3: return launchTiledXOne< U, 3 >(count, Kt, K, s);
+    case 4: return launchTiledXOne< U, 4 >(count, Kt, K, s);
+    case 5: return launchTiledXOne< U, 5 >(count, Kt, K, s);
+    case 6: return launchTiledXOne< U, 6 >(count, Kt, K, s);
+    case 7: return launchTiledXOne< U, 7 >(count, Kt, K, s);
+    case 8: return launchTiledXOne< U, 8 >(count, Kt, K, s);
+    default: return 1;
+    }
+}
+// `count` element matrices: x-major tiled (d_Kt, formed with ElemArgs::K_tiled == 2) -> row-major, bitwise symmetric (d_K), on stream s
+int launchTiledXToRowMajorSym(int U, int N1, int64_t count, const double* d_Kt, double* d_K, hipStream_t s)
+{
+    const int64_t blocks = ((count + 7) / 8) * 8 * int64_t(N1) * N1;
+    if (blocks > int64_t(0x7fffffff) || U < 1 || U > 4 || N1 < 2 || N1 > 8)
+    {
+        setError("x-major tiled -> row-major: shape (order %d, %d unknowns, %lld elements) not supported", N1 - 1, U, (long long)count);
         return -1;
     }
-    hipLaunchKernelGGL(symmetriseKernel, dim3(unsigned(blocks)), dim3(256), 0, s, d_K, Nd);
-    if (hipGetLastError() != hipSuccess)
+    int rc = 1;
+    switch (U)
     {
-        setError("symmetrise kernel launch failed");
+    case 1: rc = launchTiledXU< 1 >(N1, count, d_Kt, d_K, s); break;
+    case 2: rc = launchTiledXU< 2 >(N1, count, d_Kt, d_K, s); break;
+    case 3: rc = launchTiledXU< 3 >(N1, count, d_Kt, d_K, s); break;
+    case 4: rc = launchTiledXU< 4 >(N1, count, d_Kt, d_K, s); break;
+    default: break;
+    }
+    if (rc || hipGetLastError() != hipSuccess)
+    {
+        setError("x-major tiled -> row-major kernel launch failed (order %d, %d unknowns)", N1 - 1, U);
         return -3;
     }
     return 0;

@@ -109,7 +109,11 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel
         kern(in, res);
         // records of one element as [entry][q] (structure of arrays): neighbouring threads = neighbouring quadrature points
         // write, and the assembly kernels read, neighbouring addresses
-        double* c = cbuf + el * NQP * CS + q;
+        // K_tiled == 2 (the x-major tiled layout, api_assembled.hip): the records of the element with the roles of x and z exchanged --
+        // point (qx, qy, qz) at position (qz, qy, qx), the xi and the zeta derivative exchanged; the 1-D tables are the same in the
+        // three directions, so the assembly kernel then forms the same K_e with x and z exchanged in its loops and in its layout
+        const bool xz = a.K_tiled == 2;
+        double*    c  = cbuf + el * NQP * CS + (xz ? qz + NQ * (qy + NQ * qx) : q);
 #pragma unroll
         for (int e_ = 0; e_ < E; ++e_)
 #pragma unroll
@@ -118,8 +122,8 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void assembleCoeffKernel
                 c[((e_ * U + u) * 4 + 0) * NQP] = res.operators[0](e_, u);
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    c[((e_ * U + u) * 4 + 1 + d) * NQP] = res.operators[1](e_, u) * Ji[d][0] + res.operators[2](e_, u) * Ji[d][1] +
-                                                          res.operators[3](e_, u) * Ji[d][2];
+                    c[((e_ * U + u) * 4 + 1 + (xz ? 2 - d : d)) * NQP] = res.operators[1](e_, u) * Ji[d][0] + res.operators[2](e_, u) * Ji[d][1] +
+                                                                         res.operators[3](e_, u) * Ji[d][2];
             }
         c[(CS - 1) * NQP] = qw[qx] * qw[qy] * qw[qz] * det;
         if (!(det > 0.)) // reference: "Encountered degenerate element ( |J| <= 0 )" (AssembleLocalSystem.hpp:249)
@@ -652,6 +656,10 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
 
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
+    // K_tiled == 2 (the x-major tiled layout, read by the mirroring transposition of api_assembled.hip): only the rows whose column
+    // line (iteration, by') does not lie behind their row line (slot, by) are formed and stored -- slots below the iteration drop
+    // out as whole waves where a slot's rows fill whole waves (order 6), the slot of the iteration stores its rows by' <= by
+    [[maybe_unused]] const bool lower = TILED && a.K_tiled == 2;
 
     // DPPT: the 1-D tables of stage 3 (I, D and the even-odd tables of I^T, D^T) as DPP-row operands instead of scalar loads
     constexpr bool DPPT  = C::dpp2(TILED, BLOCKS); // (the one-launch kernel for the stored row-major matrices keeps the scalar tables)
@@ -771,7 +779,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                     }
 #pragma unroll
                 for (int sl = 0; sl < N1; ++sl)
-                    if (sl < nsl_)
+                    if (sl < nsl_ && !(lower && sl < it_))
                     {
                         int bx_, bxp_;
                         slotPairAt(it_, sl, bx_, bxp_);
@@ -871,6 +879,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                 pp          = has_row ? pp : 0;
             }
         }
+        if constexpr (TILED)
+            has_row = has_row && !(lower && (pp < iter || (pp == iter && byp > by)));
         int bx_row, bxp;
         slotPair(pp, bx_row, bxp);
         const int bb = by + N1 * byp; // pair index of the y product tables
@@ -883,6 +893,8 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         for (int it = tid; it < n_slots * NQ * NQ; it += NT)
         {
             const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ); // (bx: the slot)
+            if (lower && bx < iter)
+                continue;
             int       bx1, bx1p;
             slotPair(bx, bx1, bx1p);
             const int pair = bx1p * N1 + bx1; // pair index (bx, bx') = bx + N1 bx' of the x product table
@@ -925,7 +937,9 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         // (DPPT: whole waves run stages 2 and 3 -- a DPP operand comes from a lane of the row that must be active; lanes without a
         // row work on row 0 and are masked where results leave the registers)
         const int  n_rows_iter = !DIAG ? ROWS : (two_lists ? 2 * NTRI : NTRI) + (n_slots - (two_lists ? 2 : 1)) * N2;
-        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter && !is_producer : (tid & ~63) < n_rows_iter;
+        // (lower: a wave whose last 16-lane unit belongs to a slot below the iteration has no row to form)
+        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter && !is_producer && !(lower && ((tid >> 6) * 4 + 3) / C::UNITS < iter)
+                                      : (tid & ~63) < n_rows_iter;
         if (DPPT ? wave_rows : has_row)
         {
             // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]

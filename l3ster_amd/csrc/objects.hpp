@@ -246,7 +246,7 @@ const KernelMeta* findResidual(int id);
 // api_assembled.hip: `count` element matrices from the tiled layout of l3k_local_assemble_tiled to the row-major one, on stream s
 int launchTiledToRowMajor(int U, int N1, int64_t count, const double* d_Kt, double* d_K, hipStream_t s);
 // ... and the upper triangles overwritten by the mirrored lower ones (bitwise symmetric matrices, as the reference's)
-int launchSymmetrise(int Nd, int64_t count, double* d_K, hipStream_t s);
+int launchTiledXToRowMajorSym(int U, int N1, int64_t count, const double* d_Kt, double* d_K, hipStream_t s);
 // api_assembled.hip: the batch scatter of element systems into CSR values on a given stream
 int launchAssembledScatter(l3k_mf* mf, int64_t first, int64_t count, const double* d_K, const double* d_F, const int64_t* d_row_ptr,
                            const int32_t* d_col_ind, double* d_values, double* d_rhs, size_t ldr, int skip_dirichlet,

@@ -351,13 +351,16 @@ def test_rhs_scatter_with_more_than_64_rhs_entries_per_node(ctx, mode):
 
 @pytest.mark.parametrize("kid,ne,p,vo,kpar", [(system.KERNEL_DIFFUSION3D, (3, 2, 2), 2, 1, [0.7, 1.3]), (system.KERNEL_DIFFUSION3D, (2, 2, 1), 4, 1, [1.0, 1.0]),
                                               (system.KERNEL_DIFFUSION3D, (2, 1, 1), 6, 1, [0.7, 1.3]), (system.KERNEL_MASS3D, 2, 3, 2, None),
-                                              (system.KERNEL_DIVCURL3D, (2, 1, 1), 4, 1, [0.6]), (system.KERNEL_ADVECTION3D, 2, 4, 1, [0.05])])
+                                              (system.KERNEL_DIVCURL3D, (2, 1, 1), 4, 1, [0.6]), (system.KERNEL_ADVECTION3D, 2, 4, 1, [0.05]),
+                                              (system.KERNEL_DIFFUSION3D, (2, 2, 1), 1, 1, [1.0, 1.0]), (system.KERNEL_DIFFUSION3D, (2, 2, 1), 3, 1, [0.7, 1.3]),
+                                              (system.KERNEL_DIFFUSION3D, (2, 1, 1), 5, 1, [1.0, 1.0]), (system.KERNEL_DIFFUSION3D, (2, 1, 1), 7, 1, [0.7, 1.3])])
 def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
     """l3k_local_assemble(K) -- the stand-in for assembleLocalSystem's return value (row-major K_e, AssembleLocalSystem.hpp:168-182) --
-    forms the matrices in the tiled layout and turns them with a transposition kernel on a second stream, sub-batch by sub-batch,
-    then mirrors the lower triangle (round 4; the assembly kernel's own row-major stores fill an eighth of each 64-byte line per
-    instruction).  The routes agree: default == tiled + transposition without the mirror pass to rounding == the direct store to
-    rounding; the default is symmetric bit for bit like the reference's matrix; several sub-batches give the same bits as one."""
+    forms the matrices in the x-major tiled layout and turns them with the one-pass mirroring transposition kernel on a second
+    stream, sub-batch by sub-batch (round 4; the assembly kernel's own row-major stores fill an eighth of each 64-byte line per
+    instruction).  The routes agree: default == plain tiled layout + plain transposition (K[i][j], K[j][i] in two summation orders)
+    to rounding == the direct store to rounding; the default is symmetric bit for bit like the reference's matrix; several
+    sub-batches give the same bits as one."""
     info = system.kernel_info(kid)
     U, F = info["n_unknowns"], info["n_fields"]
     part = system.CubePartition(ne, p, perturb=0.15)
@@ -376,7 +379,7 @@ def test_stored_row_major_routes_agree(ctx, kid, ne, p, vo, kpar):
     # (the default route: tiled + transposition from order 4, the direct store below -- small matrices)
     assert torch.equal(K0, K1 if p >= 4 else K3)
     assert torch.equal(K1, K1.transpose(1, 2)) and torch.equal(K3, K3.transpose(1, 2))
-    assert torch.equal(torch.tril(K1), torch.tril(K2))  # the mirror pass only rewrites the upper triangle
+    assert float((K1 - K2).abs().amax()) < 1e-13 * scale
     assert float((K2 - K2.transpose(1, 2)).abs().amax()) < 1e-13 * scale
     assert float((K1 - K3).abs().amax()) < 1e-13 * scale
     # a sub-range with an offset, and the checksum beside the stored matrices

@@ -140,14 +140,12 @@ if os.path.isdir(os.path.join(SRC, "o6_tcc")):
 if os.path.isdir(os.path.join(SRC, "asm_fetch")):  # round 4: the stored route is three kernels (tools/r04_stored_assembly.py runs all routes)
     alg = 64 * 1372 * 1372 * 8
     with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
-        out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE | FETCH_SIZE> --kernel-trace -- python tools/r04_stored_assembly.py --orders 6 --batch 64 --steps 2\n"
-                  "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each), row-major, per KERNEL of the routes; mean per launch.  The direct store\n"
-                  "# is one launch over the 64 matrices (963.7 MB); the round-4 route runs as 4 pipelined sub-batches of 16 matrices (240.9 MB per launch)\n"
-                  "# (direct store = assembleSumfactKernel<..., false, 0> with K; round-4 default = assembleSumfactKernel<..., true, 0> (tiled) + tiledToRowMajorKernel + symmetriseKernel)\n")
+        out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE | FETCH_SIZE> --kernel-trace -- python tools/r04_stored_assembly.py --orders 6 --batch 64 --steps 2 --routes direct_store,x_tiled_one_pass_symmetric\n"
+                  "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each, 963.7 MB per launch), row-major, per KERNEL of the two routes; mean per launch\n"
+                  "# (direct store = assembleSumfactKernel<..., false, 0> with K; default = assembleSumfactKernel<..., true, 0> (x-major tiled layout, lower triangle only) + tiledXToRowMajorSymKernel)\n")
         for label, pred, n_mat in (("direct row-major store (assembleSumfactKernel<.., false, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "false, 0>" in nme, 64),
-                                   ("tiled store (assembleSumfactKernel<.., true, 0>), 16 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme, 16),
-                                   ("tiledToRowMajorKernel, 16 matrices per launch", lambda nme: "tiledToRowMajorKernel" in nme, 16),
-                                   ("symmetriseKernel, 16 matrices per launch (reads the lower, writes the upper triangles)", lambda nme: "symmetriseKernel" in nme, 16)):
+                                   ("x-major tiled store of the lower triangle (assembleSumfactKernel<.., true, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme, 64),
+                                   ("tiledXToRowMajorSymKernel (reads the lower triangle once, writes every entry and its mirror image), 64 matrices per launch", lambda nme: "tiledXToRowMajorSymKernel" in nme, 64)):
             mk, nk = counters_of(["asm_tcc", "asm_write", "asm_fetch"], pred)
             if not mk:
                 continue

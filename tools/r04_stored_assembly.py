@@ -1,7 +1,8 @@
 """Stored LocalAssembly in the reference's layout (row-major K_e, AssembleLocalSystem.hpp:168-182) -- VERDICT r3 item 7: the three
 routes of l3k_local_assemble(K) at orders 6 / 4 / 2: the assembly kernel's direct row-major store (round 3: 8-byte stores at a 32-byte
 stride, 3.9 x write traffic), tiled + transposition kernel on a second stream (no symmetrisation: K symmetric to rounding), and the
-default, the same + the pass that mirrors the lower triangle (bitwise symmetric like the reference's).  One JSON line per order.
+default: the x-major tiled layout + the one-pass transposition that reads the lower triangle and writes every entry twice (bitwise
+symmetric like the reference's).  One JSON line per order.
 
     python tools/r04_stored_assembly.py [--batch 256] > profiles/r04_stored_assembly.jsonl
 """
@@ -21,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--orders", default="6,4,2")
+ap.add_argument("--routes", default="direct_store,tiled_transposed,x_tiled_one_pass_symmetric", help="(profiles: one tiled route per run keeps the per-kernel means apart)")
 a = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
@@ -37,7 +39,9 @@ for p in [int(s) for s in a.orders.split(",")]:
     out = {"order": p, "batch": batch, "matrix_bytes": Nd * Nd * 8}
     ref = None
     for name, tune in (("direct_store", dict(assemble_direct_store=1)), ("tiled_transposed", dict(assemble_no_symmetrise=1)),
-                       ("tiled_transposed_symmetrised", dict())):
+                       ("x_tiled_one_pass_symmetric", dict())):
+        if name not in a.routes.split(","):
+            continue
         with ctx.tuning(**tune):
             check = lambda rc: None
             from l3ster_amd import capi
