@@ -346,44 +346,55 @@ __global__ __launch_bounds__(256) void tiledXToRowMajorSymKernel(const double* _
     const int     tid = threadIdx.x;
     const double* Te  = Kt + e * int64_t(Nd) * Nd;
     double*       Ke  = K + e * int64_t(Nd) * Nd;
+    // (no run-time divisions: wave w takes the runs / rows w, w + 4, ..., lane x the entries x, x + 64, ... of a run / row)
+    const int wv = tid >> 6, x = tid & 63;
     for (int bzp = 0; bzp <= bz; ++bzp)
     {
-        const int run   = bzp < bz ? N2 : (by + 1) * N1; // column nodes (by', bx') of the slab on lines l' <= l
-        const int total = U * U * N1 * run;
-        constexpr int NB = 8; // independent loads in flight per thread
-        for (int t0 = tid; t0 < total; t0 += 256 * NB)
-        {
-            double v[NB];
-            int    dst[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
+        const int run = bzp < bz ? N2 : (by + 1) * N1; // column nodes (by', bx') of the slab on lines l' <= l
+        constexpr int NR = U * U * N1;                 // runs (u, u', bx) of this x-line in the slab
+        constexpr int NB = 8;                          // independent loads in flight per thread
+        const double* Ts = Te + (int64_t(bzp) * N1 * N1 + bz) * N1 * N2 + by * N2; // + ((uu * N1 * N1 + bx) * N1) * N1 * N2
+        for (int r0 = wv; r0 < NR; r0 += 4 * NB)
+            for (int j = x; j < run; j += 64)
             {
-                const int t = t0 + 256 * k;
-                if (t < total)
+                double v[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
                 {
-                    const int j = t % run, r = t / run, bx = r % N1, uu = r / N1, u = uu / U, up = uu - u * U;
-                    v[k]   = Te[((((int64_t(uu) * N1 + bzp) * N1 + bx) * N1 + bz) * N1 + by) * N2 + j];
-                    dst[k] = (bx * U + u) * LD + j * U + up;
+                    const int r = r0 + 4 * k;
+                    if (r < NR)
+                    {
+                        const int bx = r % N1, uu = r / N1;
+                        v[k]         = Ts[((int64_t(uu) * N1 * N1 + bx) * N1) * N1 * N2 + j];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                {
+                    const int r = r0 + 4 * k;
+                    if (r < NR)
+                    {
+                        const int bx = r % N1, uu = r / N1, u = uu / U, up = uu - u * U;
+                        tile[(bx * U + u) * LD + j * U + up] = v[k];
+                    }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (t0 + 256 * k < total)
-                    tile[dst[k]] = v[k];
-        }
         __syncthreads();
         const int ncol = run * U;
-        for (int o = tid; o < R * ncol; o += 256)
+        for (int r = wv; r < R; r += 4)
         {
-            const int r = o / ncol, c = o - r * ncol;
-            double    v = tile[r * LD + c];
-            if (bzp == bz)
+            double* const out = Ke + (int64_t(l) * R + r) * Nd + bzp * CW;
+            for (int c = x; c < ncol; c += 64)
             {
-                const int cc = c - by * R; // position within the line block l' == l: its upper part comes from the mirror position
-                if (cc > r)
-                    v = tile[cc * LD + by * R + r];
+                double v = tile[r * LD + c];
+                if (bzp == bz)
+                {
+                    const int cc = c - by * R; // position within the line block l' == l: its upper part comes from the mirror position
+                    if (cc > r)
+                        v = tile[cc * LD + by * R + r];
+                }
+                out[c] = v;
             }
-            Ke[(int64_t(l) * R + r) * Nd + bzp * CW + c] = v;
         }
         const int nm = (bzp < bz ? N2 : by * N1) * U; // rows of the mirror image (the line block l' == l has none)
         for (int o = tid; o < nm * R; o += 256)

@@ -537,10 +537,15 @@ struct Stage2Items
 // BLOCKS: 0 every pair u' <= u of unknowns (TILED: every pair), 1 the diagonal blocks u' == u only, 2 the off-diagonal ones only --
 // as kernels of their own the two kinds of iteration below get a register allocation each (both in one kernel: 302 k matrices/s at
 // order 6; separately 1.04 + 2.22 us per element of which 0.5 counted twice)
-template < typename K, int P, int NQ, bool TILED = false, int BLOCKS = 0 >
-__global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
+// TMODE: 0 row-major / streaming, 1 the tiled layout (TILED), 2 the x-major tiled layout, lower triangle only (TILED with the
+// diagonal-block kernel's merged iterations for ALL U x U blocks: the pairs bx' <= bx in n / 2 + 1 iterations of n slots, the
+// slots with bx' == bx with their rows by' <= by -- the half "column line (bx', by') not behind the row line (bx, by)" that the
+// mirroring transposition of api_assembled.hip reads; bx here is the kernel's first index, the element's z after the exchange)
+template < typename K, int P, int NQ, int TMODE = 0, int BLOCKS = 0 >
+__global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TMODE != 0, BLOCKS))) void assembleSumfactKernel(const ElemArgs a, const double* __restrict__ cbuf,
                                                                                        int64_t elem0, int xcd_group)
 {
+    constexpr bool TILED = TMODE != 0;
     constexpr KernelParams params = K::params;
     constexpr int          U = params.n_unknowns, E = params.n_equations;
     using C = SfAsmCfg< P, NQ >;
@@ -656,10 +661,6 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
 
     double  csum = 0.;
     double* Kel  = a.K ? a.K + (elem0 + el) * int64_t(ND) * ND : nullptr;
-    // K_tiled == 2 (the x-major tiled layout, read by the mirroring transposition of api_assembled.hip): only the rows whose column
-    // line (iteration, by') does not lie behind their row line (slot, by) are formed and stored -- slots below the iteration drop
-    // out as whole waves where a slot's rows fill whole waves (order 6), the slot of the iteration stores its rows by' <= by
-    [[maybe_unused]] const bool lower = TILED && a.K_tiled == 2;
 
     // DPPT: the 1-D tables of stage 3 (I, D and the even-odd tables of I^T, D^T) as DPP-row operands instead of scalar loads
     constexpr bool DPPT  = C::dpp2(TILED, BLOCKS); // (the one-launch kernel for the stored row-major matrices keeps the scalar tables)
@@ -779,7 +780,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                     }
 #pragma unroll
                 for (int sl = 0; sl < N1; ++sl)
-                    if (sl < nsl_ && !(lower && sl < it_))
+                    if (sl < nsl_)
                     {
                         int bx_, bxp_;
                         slotPairAt(it_, sl, bx_, bxp_);
@@ -879,10 +880,10 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                 pp          = has_row ? pp : 0;
             }
         }
-        if constexpr (TILED)
-            has_row = has_row && !(lower && (pp < iter || (pp == iter && byp > by)));
         int bx_row, bxp;
         slotPair(pp, bx_row, bxp);
+        if constexpr (TILED) // (position of the row in the tiled layout: by its pair's bx, not by its slot)
+            row_t = bx_row * N2 + by * N1 + byp;
         const int bb = by + N1 * byp; // pair index of the y product tables
         // ---- stage 1: A[bx][g][qz][qy] for the pairs (bx, bx' = bxp): one thread per (bx, qy, qz) forms all nine groups from its
         // 16 x nq entries of G and the 4 x nq entries of the x product table of its pair -- one straight-line body of 16
@@ -893,8 +894,6 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         for (int it = tid; it < n_slots * NQ * NQ; it += NT)
         {
             const int bx = it / (NQ * NQ), qyz = it - bx * (NQ * NQ); // (bx: the slot)
-            if (lower && bx < iter)
-                continue;
             int       bx1, bx1p;
             slotPair(bx, bx1, bx1p);
             const int pair = bx1p * N1 + bx1; // pair index (bx, bx') = bx + N1 bx' of the x product table
@@ -937,9 +936,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         // (DPPT: whole waves run stages 2 and 3 -- a DPP operand comes from a lane of the row that must be active; lanes without a
         // row work on row 0 and are masked where results leave the registers)
         const int  n_rows_iter = !DIAG ? ROWS : (two_lists ? 2 * NTRI : NTRI) + (n_slots - (two_lists ? 2 : 1)) * N2;
-        // (lower: a wave whose last 16-lane unit belongs to a slot below the iteration has no row to form)
-        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter && !is_producer && !(lower && ((tid >> 6) * 4 + 3) / C::UNITS < iter)
-                                      : (tid & ~63) < n_rows_iter;
+        const bool wave_rows   = DPP2 ? (tid >> 6) * 4 < n_units_iter && !is_producer : (tid & ~63) < n_rows_iter;
         if (DPPT ? wave_rows : has_row)
         {
             // ---- stage 2 in registers: B[tz][qz] = sum_{ty} sum_qy P[ty][(by,by')][qy] A[(ty,tz)][qz][qy]
@@ -1161,7 +1158,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
                             if constexpr (TILED)
                             {
                                 constexpr int64_t NNc = int64_t(N1) * N2;
-                                if (has_row)
+                                if (has_row && !(DIAG && rdlt == 0 && bzp > bz)) // (TMODE 2: bx' == bx, by' == by: the columns bz' <= bz)
                                     Kel[(u * U + up) * NNc * NNc + ((int64_t(bxp) * N1 + bz) * ROWS + row_t) * N1 + bzp] = m;
                             }
                             else if (Kel && !skip && has_row)
@@ -1199,7 +1196,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TILED, BLOCKS))) voi
         __syncthreads(); // A is rewritten by the next iteration
     }
     };
-    iterations.template operator()< BLOCKS == 1 >();
+    iterations.template operator()< BLOCKS == 1 || TMODE == 2 >();
     if (a.checksum)
     {
         // fixed-order reduction over the workgroup, one atomic per workgroup
@@ -1254,11 +1251,13 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
             if constexpr (S::feasible)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ >),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 0))) == hipSuccess &&
-                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, true >),
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, 1 >),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(true, 0))) == hipSuccess &&
-                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 1 >),
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, 2 >),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(true, 0))) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, 0, 1 >),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 1))) == hipSuccess &&
-                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, false, 2 >),
+                     hipFuncSetAttribute(reinterpret_cast< const void* >(assembleSumfactKernel< K, P, NQ, 0, 2 >),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, int(S::ldsFor(false, 2))) == hipSuccess;
             if (!ok)
             {
@@ -1314,15 +1313,17 @@ int launchAssemble(const ElemArgs& a, const void* kparam_blob, hipStream_t strea
             // where the workgroups of an element should meet in one L2 (stored row-major matrices) or on request
             const bool one_launch = a.K != nullptr && !tune.assemble_two_launches;
             int        rc         = 0;
-            if (a.K_tiled)
-                rc = launch(assembleSumfactKernel< K, P, NQ, true >, U * U, S::threadsFor(true, 0), S::ldsFor(true, 0));
+            if (a.K_tiled == 2)
+                rc = launch(assembleSumfactKernel< K, P, NQ, 2 >, U * U, S::threadsFor(true, 0), S::ldsFor(true, 0));
+            else if (a.K_tiled)
+                rc = launch(assembleSumfactKernel< K, P, NQ, 1 >, U * U, S::threadsFor(true, 0), S::ldsFor(true, 0));
             else if (one_launch)
                 rc = launch(assembleSumfactKernel< K, P, NQ >, U * (U + 1) / 2, S::threadsFor(false, 0), S::ldsFor(false, 0));
             else
             {
-                rc = launch(assembleSumfactKernel< K, P, NQ, false, 2 >, U * (U - 1) / 2, S::threadsFor(false, 2), S::ldsFor(false, 2));
+                rc = launch(assembleSumfactKernel< K, P, NQ, 0, 2 >, U * (U - 1) / 2, S::threadsFor(false, 2), S::ldsFor(false, 2));
                 if (rc == 0)
-                    rc = launch(assembleSumfactKernel< K, P, NQ, false, 1 >, U, S::threadsFor(false, 1), S::ldsFor(false, 1));
+                    rc = launch(assembleSumfactKernel< K, P, NQ, 0, 1 >, U, S::threadsFor(false, 1), S::ldsFor(false, 1));
             }
             if (rc)
                 return rc;

@@ -142,9 +142,9 @@ if os.path.isdir(os.path.join(SRC, "asm_fetch")):  # round 4: the stored route i
     with open(os.path.join(DST, f"{tag}_tcc_assembly_stored.txt"), "w") as out:
         out.write("# rocprofv3 --pmc <TCC set | WRITE_SIZE | FETCH_SIZE> --kernel-trace -- python tools/r04_stored_assembly.py --orders 6 --batch 64 --steps 2 --routes direct_store,x_tiled_one_pass_symmetric\n"
                   "# 64 element matrices of 1372 x 1372 doubles (15.06 MB each, 963.7 MB per launch), row-major, per KERNEL of the two routes; mean per launch\n"
-                  "# (direct store = assembleSumfactKernel<..., false, 0> with K; default = assembleSumfactKernel<..., true, 0> (x-major tiled layout, lower triangle only) + tiledXToRowMajorSymKernel)\n")
-        for label, pred, n_mat in (("direct row-major store (assembleSumfactKernel<.., false, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "false, 0>" in nme, 64),
-                                   ("x-major tiled store of the lower triangle (assembleSumfactKernel<.., true, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and "true, 0>" in nme, 64),
+                  "# (direct store = assembleSumfactKernel<..., 0, 0> with K; default = assembleSumfactKernel<..., 2, 0> (x-major tiled layout, lower triangle only) + tiledXToRowMajorSymKernel)\n")
+        for label, pred, n_mat in (("direct row-major store (assembleSumfactKernel<.., 0, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and ", 0, 0>" in nme, 64),
+                                   ("x-major tiled store of the lower triangle (assembleSumfactKernel<.., 2, 0>), 64 matrices per launch", lambda nme: "assembleSumfactKernel" in nme and ", 2, 0>" in nme, 64),
                                    ("tiledXToRowMajorSymKernel (reads the lower triangle once, writes every entry and its mirror image), 64 matrices per launch", lambda nme: "tiledXToRowMajorSymKernel" in nme, 64)):
             mk, nk = counters_of(["asm_tcc", "asm_write", "asm_fetch"], pred)
             if not mk:
