@@ -313,6 +313,20 @@ def main():
             rate = assembly_rate(n_sweep)
             with ctx.tuning(assemble_dense=1):
                 rate_dense = assembly_rate(min(1536, n_sweep), 512)
+            # the reference's return value itself: row-major K_e stored in HBM, symmetric bit for bit (AssembleLocalSystem.hpp:168-182), 256
+            # matrices (x-major tiled assembly of the lower triangle + the mirroring transposition: DESIGN.md 4.4)
+            n_st = min(256, n_sweep)
+            Kst = torch.empty((n_st, (p + 1) ** 3 * U, (p + 1) ** 3 * U), dtype=torch.float64, device=dev)
+            amf.local_assemble_into(Kst, 0, n_st)
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(3):
+                amf.local_assemble_into(Kst, 0, n_st)
+            s1.record()
+            torch.cuda.synchronize()
+            rate_stored = 3 * n_st / (s0.elapsed_time(s1) * 1e-3)
+            stored_symmetric = bool(torch.equal(Kst[:4], Kst[:4].transpose(1, 2)))
+            del Kst
             nd, kd = (p + 1) ** 3 * U, (p + 1) ** 3 * 7
             dense_flops = kd * nd * (nd + 1)          # symmetric half of 2*K*N^2
             sf_flops = SUMFACT_ASSEMBLY_FLOP_PER_ELEM  # executed by the sum-factorised kernel (order 6, U = 4, E = 7)
@@ -326,6 +340,9 @@ def main():
                                                               "on this part (78.6 TFLOP/s, profiles/r02_fp64_vector_matrix_coexecution.log)"
                                                               % (sf_flops / 1e6),
                                                      "dense_equivalent_tflops": rate * dense_flops / 1e12},
+                                        "stored_row_major": {"value": rate_stored, "unit": "element matrices/s", "batch": n_st,
+                                                             "bitwise_symmetric": stored_symmetric,
+                                                             "GB_per_s_of_matrices": rate_stored * nd * nd * 8 / 1e9},
                                         "dense_mfma_kernel": {"value": rate_dense, "unit": "element matrices/s",
                                                               "roofline": {"bound": "mfma", "achieved": rate_dense * dense_flops / 1e12,
                                                                            "peak": 78.6, "unit": "TFLOP/s",

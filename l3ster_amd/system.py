@@ -618,6 +618,15 @@ class MatrixFreeSystem:
         check(capi.load().l3k_local_assemble(self._h, first, count, _ptr(K), _ptr(F), _ptr(cs)))
         return K, F, cs
 
+    def local_assemble_into(self, K, first=0, count=None):
+        """The element matrices of [first, first + count) into the caller's tensor K [count, Nd, Nd] (row-major, bitwise symmetric)."""
+        count = K.shape[0] if count is None else count
+        Nd = (self.mesh.part.order + 1) ** 3 * self.info["n_unknowns"]
+        if tuple(K.shape[1:]) != (Nd, Nd) or K.shape[0] < count or not K.is_contiguous() or str(K.dtype) != "torch.float64":
+            raise L3KError(f"local_assemble_into: K must be a contiguous float64 tensor [>= {count}, {Nd}, {Nd}]")
+        check(capi.load().l3k_local_assemble(self._h, first, count, _ptr(K), None, None))
+        return K
+
     def assembled_scatter(self, K, F, row_ptr, col_ind, values, rhs, first=0, skip_dirichlet=False):
         """scatterLocalSystem for the batch [first, first + len(K)) (algsys/ScatterLocalSystem.hpp:24-54): K [count, Nd, Nd]
         and F [count, n_rhs, Nd] as local_assemble returns them, summed into `values` (over the caller's CSR graph
