@@ -235,6 +235,33 @@ def test_config3_full_streaming_sweep_64cubed_order6(ctx):
         assert abs(cs[e] - ref) < 1e-10 * float((np.abs(Y) * wgt).sum()), (e, cs[e], ref)
 
 
+def test_config3_stored_row_major_order6_vs_oracle_and_rate(ctx):
+    """Config 3's matrices as the reference returns them -- row-major K_e stored in HBM, symmetric bit for bit -- for 128 elements of
+    the 64^3 order-6 mesh in one call (x-major tiled assembly of the lower triangle + mirroring transposition, two sub-batches): two
+    matrices entrywise against the oracle's local-element assembly, all of them bitwise symmetric, and a floor on the rate (98 k
+    matrices/s measured; the round's first route gave 66 k, the assembly kernel's direct store 42 k)."""
+    p, U, kpar, n = 6, 4, [1.0, 1.0], 128
+    part = system.CubePartition(64, p, perturb=0.1)
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U), system.KERNEL_DIFFUSION3D, kpar)
+    Nd = (p + 1) ** 3 * U
+    first = 70_000
+    K = torch.empty((n, Nd, Nd), dtype=torch.float64, device="cuda")
+    mf.local_assemble_into(K, first, n)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(3):
+        mf.local_assemble_into(K, first, n)
+    t1.record()
+    torch.cuda.synchronize()
+    rate = 3 * n / (t0.elapsed_time(t1) * 1e-3)
+    assert torch.equal(K, K.transpose(1, 2))
+    for i in (0, 101):  # (one element of each sub-batch)
+        Kref, _ = O.assemble_local(system.KERNEL_DIFFUSION3D, p, p + 1, 1, part.elem_verts[first + i], kparams=kpar)
+        got = K[i].cpu().numpy()
+        assert np.abs(got - Kref).max() < 1e-12 * np.abs(Kref).max()
+    assert rate > 60_000, rate
+
+
 def _csr_graph(part, dpn, field_inds):
     """CSR graph of the rank-local matrix: row / column dofs of every element coupled (what the reference's sparsity graph
     holds for one domain kernel), columns ascending -- built on the host like the caller's Tpetra graph would be."""
