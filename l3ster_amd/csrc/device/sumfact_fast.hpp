@@ -244,7 +244,12 @@ struct FastCfg
 #ifdef L3K_FAST_PS
     static constexpr int PS = M == 7 ? L3K_FAST_PS : M * M, OS = PS * M;
 #else
-    static constexpr int PS = M * M, OS = PS * M;
+    // plane stride: M * M, padded where that removes bank conflicts (16-byte units, 16 consecutive lanes per LDS pass: the unit
+    // index modulo 16 must be distinct among them).  M = 8: stride 64 = 0 (mod 16) put the eight x-pencils of a lane row on ONE
+    // bank group (8-way conflicts on the x-oriented accesses: 352 -> 128 LDS passes per element and field group with 65); M = 6:
+    // 90 -> 66 with 41; M = 4: 144 -> 64 with 19.  M = 7 (49 = 1 mod 16: one orientation 2.5-way) and M = 5 have no better stride,
+    // and at M = 7 the LDS has no room (7 waves per CU).  Model: tools/lds_bank_model.py
+    static constexpr int PS = M == 8 ? 65 : (M == 6 ? 41 : (M == 4 ? 19 : M * M)), OS = PS * M;
 #endif
     static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
     // per team: bufA | bufB (NG groups of OS double2 each) | vertices
