@@ -53,6 +53,17 @@ public:
     // bitwise-reproducible element launches for the meshes created from now on (the reference's relaxed atomics,
     // algsys/MatrixFreeSystem.hpp:513, are not reproducible run to run)
     void     setDeterministic(bool on = true) { check(l3k_ctx_set_deterministic(m_ctx, on ? 1 : 0)); }
+    // the point a domain kernel sees under sum factorisation: the true z (default) or the reference's z = 0
+    // (algsys/SumFactorization.hpp:732)
+    void setReferenceZ0(bool on = true) { check(l3k_ctx_set_reference_z0(m_ctx, on ? 1 : 0)); }
+    // launch-route settings (the defaults are the measured choices; tests and tools take the other routes on purpose)
+    l3k_tuning tuning() const
+    {
+        l3k_tuning t{};
+        check(l3k_ctx_get_tuning(m_ctx, &t));
+        return t;
+    }
+    void setTuning(const l3k_tuning& t) { check(l3k_ctx_set_tuning(m_ctx, &t)); }
     void     synchronize() { check(l3k_ctx_synchronize(m_ctx)); }
     l3k_ctx* get() const { return m_ctx; }
 
@@ -225,6 +236,7 @@ public:
     BoundaryTerm& operator=(const BoundaryTerm&) = delete;
     ~BoundaryTerm() { l3k_bnd_destroy(m_bnd); }
     void     setFields(const double* d_soa, size_t ld) { check(l3k_bnd_set_fields(m_bnd, d_soa, ld)); }
+    void     setTime(double t) { check(l3k_bnd_set_time(m_bnd, t)); } // in.point.time of the boundary kernel
     l3k_bnd* get() const { return m_bnd; }
 
 private:
@@ -266,6 +278,28 @@ std::vector< double > computeNormL2(const DeviceMesh& mesh, int residual_id, con
 // MatrixFreeSystem::updateSolution(sol_inds, sol_man, sol_man_inds) (algsys/MatrixFreeSystem.hpp:1231-1273): the solution's per-node
 // dofs sol_inds of every column into the fields sol_man_inds (index-major, one per (index, column)) of the SoA field storage that a
 // kernel's FieldAccess reads; ghost rows from d_xghost (the imported values; nullptr on a rank without ghosts)
+// computeValuesAtNodes (algsys/ComputeValuesAtNodes.hpp:217-594; the engine of setDirichletBCValues / setValues) on one rank: the
+// residual kernel evaluated at the nodes of the listed element sides (sides == nullptr: of every element), equation e written to
+// per-node dof dof_inds[e] of d_values (all local dofs), element contributions averaged; entries no listed node touches keep
+// their values.  d_work: 2 * n_local_dofs doubles of device scratch, ZEROED by the caller (sums and counts accumulate).  (A
+// partitioned host exports the ghost rows of sum and count between l3k_values_at_nodes and l3k_average_values itself.)
+template < typename KernelParamBlock >
+void computeValuesAtNodes(const DeviceMesh& mesh, int residual_id, const KernelParamBlock* params, std::span< const int > dof_inds,
+                          const CubeMesh::Sides* sides, const double* d_fields, size_t ldf, double time, int64_t n_local_dofs,
+                          double* d_values, double* d_work)
+{
+    check(l3k_values_at_nodes(mesh.ctx(), mesh.get(), residual_id, params, params ? sizeof(KernelParamBlock) : 0, d_fields, ldf, time,
+                              sides ? int64_t(sides->elems.size()) : -1, sides ? sides->elems.data() : nullptr,
+                              sides ? sides->sides.data() : nullptr, dof_inds.data(), d_work, d_work + n_local_dofs));
+    check(l3k_average_values(mesh.ctx(), d_work, d_work + n_local_dofs, n_local_dofs, d_values));
+}
+
+// NativeJacobiImpl::init (solve/NativePreconditioners.hpp:75-96): minv = sign(d) * damping / max(|d|, threshold)
+inline void jacobiInverse(const DeviceMesh& mesh, const double* d_diag, int64_t n, double* d_minv, double damping = 1., double threshold = 0.)
+{
+    check(l3k_jacobi_inverse(mesh.ctx(), d_diag, n, damping, threshold, d_minv));
+}
+
 inline void updateSolution(const DeviceMesh& mesh, const double* d_x, size_t ldx, const double* d_xghost, size_t ldxg, int ncols,
                            std::span< const int > sol_inds, std::span< const int > sol_man_inds, double* d_fields, size_t ldf, int n_fields)
 {
@@ -353,6 +387,24 @@ public:
         if (!res.converged)
             throw std::runtime_error{"Solver failed to converge"};
         return res;
+    }
+    // the n_rhs columns of a multivector one after the other (the reference hands them to Belos "Block CG")
+    std::vector< l3k_cg_result > solve(const double* d_b, size_t ldb, double* d_x, size_t ldx, int ncols, const double* d_minv,
+                                       l3k_cg_opts opts = {1e-6, 10000, 0, 1}) const
+    {
+        std::vector< l3k_cg_result > res(static_cast< size_t >(ncols));
+        check(l3k_pcg_solve_cols(m_mf, d_b, ldb, d_x, ldx, ncols, d_minv, &opts, res.data()));
+        for (const auto& r : res)
+            if (!r.converged)
+                throw std::runtime_error{"Solver failed to converge"};
+        return res;
+    }
+    // the kernel a launch of this system takes (which: 0 all / 1 interior / 2 border elements), as text
+    std::string route(int which = 0, int ncols = 1, bool with_energy = false) const
+    {
+        char buf[512] = {};
+        check(l3k_mf_route(m_mf, which, ncols, with_energy ? 1 : 0, buf, sizeof buf));
+        return buf;
     }
     // Y <- A X and d_s[1] <- <X, A X> in one pass (what a CG iteration needs of the operator; d_s: 8 device doubles)
     void applyEnergy(const double* d_x, double* d_y, double* d_s) const { check(l3k_mf_apply_energy(m_mf, d_x, d_y, d_s)); }

@@ -204,6 +204,77 @@ int main()
         std::printf("PCG: %d iterations, achieved %.2e, |Ax-b|/|b| = %.2e\n", res.iterations, res.achieved_tol, std::sqrt(e2 / b2));
         failures += !(std::sqrt(e2 / b2) < 1e-9);
     }
+    { // (4) the point a kernel sees, the launch route as text, Dirichlet values at nodes, a multivector solve
+        constexpr int   p = 2, U = 4, ne = 3;
+        l3k::CubeMesh   mesh{{ne, ne, ne}, p, {1, 1, 1}, 0, 0.1};
+        const int       unk0[1] = {0};
+        const auto      mask    = mesh.dirichletMask(U, unk0, 0x3f);
+        l3k::DeviceMesh dmesh{ctx, mesh, U, mask.data()};
+        l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params, {}, {}, 2};
+        const std::string     route = sys.route();
+        std::printf("route: %s\n", route.c_str());
+        failures += route.empty();
+        auto tune = ctx.tuning();
+        tune.generic_below = 1 << 30; // every launch on the generic kernel
+        ctx.setTuning(tune);
+        failures += sys.route().find("generic") == std::string::npos;
+        tune.generic_below = 1500;
+        ctx.setTuning(tune);
+        ctx.setReferenceZ0(true); // (Diffusion3D does not read the point: the results must not change)
+        const size_t          n = size_t(dmesh.nOwnedDofs());
+        std::vector< double > x(n);
+        for (auto& v : x)
+            v = dist(prng);
+        DevVec dx{n}, dy0{n}, dy1{n};
+        dx.up(x);
+        sys.apply(dx.p, n, dy1.p, n);
+        ctx.setReferenceZ0(false);
+        sys.apply(dx.p, n, dy0.p, n);
+        ctx.synchronize();
+        {
+            const auto y0 = dy0.down(), y1 = dy1.down(); // (atomic adds: equal to rounding, not bitwise)
+            double     d = 0., s = 0.;
+            for (size_t i = 0; i < n; ++i)
+            {
+                d = std::fmax(d, std::fabs(y0[i] - y1[i]));
+                s = std::fmax(s, std::fabs(y0[i]));
+            }
+            failures += !(d < 1e-13 * s);
+        }
+        // Dirichlet values T = x on the boundary nodes through computeValuesAtNodes (the Dirichlet value kernel of
+        // tests/Diffusion2D.hpp:49-50 in 3-D), then two right-hand sides solved as one multivector
+        const auto all = mesh.boundarySides();
+        DevVec     g{2 * n}, work{2 * n};
+        (void)hipMemset(g.p, 0, 2 * n * sizeof(double));
+        (void)hipMemset(work.p, 0, 2 * n * sizeof(double));
+        l3k::computeValuesAtNodes< DiffusionParams >(dmesh, L3K_RESIDUAL_COORDX3D, nullptr, unk0, &all, nullptr, 0, 0., int64_t(n), g.p, work.p);
+        ctx.synchronize();
+        {
+            const auto gv = g.down();
+            double     worst = 0.;
+            for (int64_t i = 0; i < mesh.view().n_owned_nodes; ++i)
+                if (mesh.view().node_boundary[i])
+                {
+                    // (node coordinates from the element vertices would need the map; the cube is perturbed in its interior only:
+                    // boundary nodes of an unperturbed boundary lie on the regular grid)
+                    const int64_t gid = mesh.view().node_grid_id[i], G = ne * p + 1;
+                    const double  X = double(gid % G) / (G - 1);
+                    worst = std::fmax(worst, std::fabs(gv[size_t(i) * U] - X));
+                }
+            std::printf("Dirichlet values at the boundary nodes: max error %.2e\n", worst);
+            failures += !(worst < 1e-12);
+        }
+        DevVec diag{n}, rhs{2 * n}, minv{n}, sol{2 * n};
+        (void)hipMemset(diag.p, 0, n * sizeof(double));
+        (void)hipMemset(rhs.p, 0, 2 * n * sizeof(double));
+        (void)hipMemset(sol.p, 0, 2 * n * sizeof(double));
+        sys.diagAndRhs(g.p, n, diag.p, rhs.p, n);
+        l3k::jacobiInverse(dmesh, diag.p, int64_t(n), minv.p);
+        const auto res = sys.solve(rhs.p, n, sol.p, n, 2, minv.p, {1e-10, 5000, 2, 1});
+        ctx.synchronize();
+        std::printf("multivector solve: %d and %d iterations\n", res[0].iterations, res[1].iterations);
+        failures += !(res.size() == 2 && res[0].converged && res[1].converged && res[1].iterations <= 1); // (column 1: zero data)
+    }
     { // (5) <x, A x> from the operator's own pass, order elevation on the device, results file round trip
         constexpr int   p = 4, U = 4, ne = 3;
         l3k::CubeMesh   mesh{{ne, ne, ne}, p, {1, 1, 1}, 0, 0.1};
