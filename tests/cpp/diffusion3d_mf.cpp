@@ -212,7 +212,7 @@ int main()
         l3k::DeviceMesh dmesh{ctx, mesh, U, mask.data()};
         l3k::MatrixFreeSystem sys{dmesh, L3K_KERNEL_DIFFUSION3D, params, {}, {}, 2};
         const std::string     route = sys.route();
-        std::printf("route: %s\n", route.c_str());
+        std::printf("route (generic_below = %lld): %s\n", (long long)ctx.tuning().generic_below, route.c_str());
         failures += route.empty();
         auto tune = ctx.tuning();
         tune.generic_below = 1 << 30; // every launch on the generic kernel
