@@ -240,7 +240,8 @@ struct FastCfg
     static constexpr int U = K::params.n_unknowns, F = K::params.n_fields, NF = U + F;
     static constexpr int NG = (NF + 1) / 2; // field groups of 2 (16-byte LDS accesses); last may be half used
     static constexpr int UG = (U + 1) / 2;
-    // LDS array strides: point (c, b, a) lives at a*PS + b*M + c (in 16-byte units within a field group)
+    static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
+    // LDS array strides: point (c, b, a) lives at b*PS + a*M + c (in 16-byte units within a field group)
 #ifdef L3K_FAST_PS
     static constexpr int PS = M == 7 ? L3K_FAST_PS : M * M, OS = PS * M;
 #else
@@ -248,10 +249,17 @@ struct FastCfg
     // index modulo 16 must be distinct among them).  M = 8: stride 64 = 0 (mod 16) put the eight x-pencils of a lane row on ONE
     // bank group (8-way conflicts on the x-oriented accesses: 352 -> 128 LDS passes per element and field group with 65); M = 6:
     // 90 -> 66 with 41; M = 4: 144 -> 64 with 19.  M = 7 (49 = 1 mod 16: one orientation 2.5-way) and M = 5 have no better stride,
-    // and at M = 7 the LDS has no room (7 waves per CU).  Model: tools/lds_bank_model.py
-    static constexpr int PS = M == 8 ? 65 : (M == 6 ? 41 : (M == 4 ? 19 : M * M)), OS = PS * M;
+    // and at M = 7 the LDS has no room (7 waves per CU).  Model: tools/lds_bank_model.py.  (Kernels with many fields keep the plain
+    // stride where the padded buffers would pass the 64 KB of a workgroup: NS3D, 14 fields, at order 2 with nq = 4.)
+    static constexpr int PS_PAD = M == 8 ? 65 : (M == 6 ? 41 : (M == 4 ? 19 : M * M));
+    static constexpr int ldsWith(int ps) // (the formula of `lds` below)
+    {
+        const int ng = (NF + 1) / 2, dg = kernelUsesFieldDers< K >() ? ng : (U + 1) / 2, os = ps * M;
+        const bool alias = dg < ng && ng - dg >= dg;
+        return 8 * EW * ((alias ? 2 * ng * os : 2 * ng * os + 2 * dg * os) + 26) + 16 * N1 * N1;
+    }
+    static constexpr int PS = ldsWith(PS_PAD) <= 64 * 1024 ? PS_PAD : M * M, OS = PS * M;
 #endif
-    static constexpr int EW = 64 / TEAM > 0 ? 64 / TEAM : 1; // elements per wave
     // per team: bufA | bufB (NG groups of OS double2 each) | vertices
     // groups whose reference derivatives reach the quadrature-point stage: all of them, or the unknowns' only
     static constexpr int    DG       = kernelUsesFieldDers< K >() ? NG : UG;
@@ -268,6 +276,9 @@ struct FastCfg
     static constexpr int    TEAM_D   = OFF_V + 24 + 2; // buffers, 8 vertices, energy accumulator (+ pad)
     static constexpr int    SLOT_B   = 16 * N1 * N1; // scatter-slot table of the mesh: [N1*N1 lanes][8] uint16, one copy per wave
     static constexpr size_t lds      = sizeof(double) * size_t(EW) * TEAM_D + SLOT_B;
+#ifndef L3K_FAST_PS
+    static_assert(lds == size_t(ldsWith(PS)));
+#endif
     static constexpr int    SG       = (64 / EW) / U * U; // lanes that scatter one element (the team's lanes + helpers): a multiple of U
     static constexpr int    NSH      = NN - (N1 - 2) * (N1 - 2) * (N1 - 2); // nodes on the element's shell
     // (any number of unknowns: an odd U leaves the second half of its last field group to the first external field, or unused)
