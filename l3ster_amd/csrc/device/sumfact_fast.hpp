@@ -311,7 +311,10 @@ struct FastCfg
 // MatrixFreeSystem.hpp:678-688): node ids, vertices, flags and the work ticket are fetched once per element, the stages run
 // once per column (the geometry is recomputed: no registers to keep 343 Jacobians).  A variant of its own, so that the
 // single-column kernel's code and register allocation stay what they are.
-template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false >
+// STRIDED: the kernel's unknowns are a subset of the node's dofs (dof = node * dofs_per_node + field_inds[u]: detail::getDofs,
+// algsys/MatrixFreeSystem.hpp:298-311): 8-byte gather and scatter accesses, every node through the atomic path (the rows of such
+// a vector hold other kernels' dofs, which the pre-scaling pass must not skip).  Plain applies only (no fused energy, one column).
+template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false, bool STRIDED = false >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -319,6 +322,21 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
     constexpr int N1 = Cfg::N1, M = Cfg::M, PS = Cfg::PS, OS = Cfg::OS, TEAM = Cfg::TEAM, EW = Cfg::EW;
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
+    static_assert(!STRIDED || (!ENERGY && !AFFINE && !MULTI));
+    [[maybe_unused]] const int dpn = a.dofs_per_node; // (STRIDED)
+    // bit u: dof u of the kernel at `node` is a Dirichlet dof
+    auto dirBits = [&](int64_t node) -> uint32_t {
+        if constexpr (STRIDED)
+        {
+            uint32_t dm = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                dm |= uint32_t(a.dirichlet[node * dpn + a.field_inds[u]] != 0) << u;
+            return dm;
+        }
+        else
+            return dirichletBits< U >(a.dirichlet, node);
+    };
     // ENERGY: x^T A x either inside the quadrature stage (sum_q wgt |B x|^2: an accumulator where no register is free) or as
     // x_e . y_e where the result leaves the registers (a second fetch of the element's x rows).  Measured per shape
 #if defined(L3K_FLAGGED_SCATTER)
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
     double        xn[N1][U];
     double        fn[N1][F > 0 ? F : 1];
     uint32_t      dm_nxt[N1];
-    const int64_t n_owned_nodes = a.n_owned_dofs / U;
+    const int64_t n_owned_nodes = a.n_owned_dofs / (STRIDED ? a.dofs_per_node : U);
     auto          elemOf = [&](int b) { return a.elem_begin + int64_t(b) * EW + team; };
     auto          valid  = [&](int b) { return (b < lim) & on_nn & ((int64_t(b) * EW + team) < a.elem_count); };
     const bool have_flags = a.elem_flags != nullptr;
@@ -459,8 +477,15 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
         for (int k = 0; k < N1; ++k)
         {
             const int64_t node = ids[k];
-            const double* p    = !SPLIT || node < n_owned_nodes ? ax + node * U : axg + (node - n_owned_nodes) * U;
-            if constexpr (U % 2 == 0)
+            const double* p    = STRIDED ? (!SPLIT || node < n_owned_nodes ? ax + node * dpn : axg + (node - n_owned_nodes) * dpn)
+                                         : (!SPLIT || node < n_owned_nodes ? ax + node * U : axg + (node - n_owned_nodes) * U);
+            if constexpr (STRIDED) // a subset of the node's dofs: one 8-byte load per unknown
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xn[k][u] = p[a.field_inds[u]];
+            }
+            else if constexpr (U % 2 == 0)
             {
 #pragma unroll
                 for (int hh = 0; hh < U / 2; ++hh)
@@ -477,7 +502,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 for (int u = 0; u < U; ++u)
                     xn[k][u] = (L3K_DBG(a) & 2) ? 1e-9 * double(node) : p[u];
             }
-            dm_nxt[k] = flagged ? dirichletBits< U >(a.dirichlet, node) : 0u;
+            dm_nxt[k] = flagged ? dirBits(node) : 0u;
 #pragma unroll
             for (int f = 0; f < F; ++f)
                 fn[k][f] = a.fields[node + f * a.ldf];
@@ -1014,7 +1039,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                     for (int k = 0; k < N1; ++k)
                     {
                         const int64_t  node = static_cast< uint32_t >(opaqueCopy(static_cast< int >(ids_cur[k])));
-                        const uint32_t dmk  = dirichletBits< U >(a.dirichlet, node) >> (2 * g);
+                        const uint32_t dmk  = dirBits(node) >> (2 * g);
                         o0[k]               = (dmk & 1u) ? 0. : o0[k];
                         o1[k]               = (dmk & 2u) ? 0. : o1[k];
                     }
@@ -1115,6 +1140,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
             constexpr int         XW = U % 2 == 0 ? 2 : 1, UX = U / XW;
             using xval_t = std::conditional_t< XW == 2, double2, double >;
             const int             sl_node = sl / U, sl_o = sl % U, sl_node2 = sl / UX, sl_o2 = XW * (sl % UX);
+            [[maybe_unused]] const int sl_f = STRIDED ? a.field_inds[sl_o] : sl_o; // (STRIDED: the node dof of this lane's unknown)
             const uint32_t* const ids1 = idsS + sl_node;
             const double* const   sb1  = sb + sl;
             const uint32_t* const ids2 = idsS + sl_node2;
@@ -1130,7 +1156,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 if ((L3K_DBG(a) & 128) && (r & 1))
                     return;
                 const int64_t node = ids1[r * (SG / U)];
-                const int64_t dof  = node * U + sl_o;
+                const int64_t dof  = STRIDED ? node * dpn + sl_f : node * U + sl_o;
                 const double  val  = sb1[r * SG];
                 double*       dst  = !SPLIT || node < n_owned_nodes ? ay + dof : ayg + (dof - a.n_owned_dofs);
                 if constexpr (FLAGGED)
@@ -1193,7 +1219,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 exclStore(dst, out);
             };
             constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * UX + SG - 1) / SG;
-            if (a.fuse_beta && !flagged)
+            if (!STRIDED && a.fuse_beta && !flagged)
             {
 #ifdef L3K_ABLATION
 #pragma unroll
@@ -1243,7 +1269,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                     }
 #endif
             }
-            else if (a.fuse_beta)
+            else if (!STRIDED && a.fuse_beta)
             {
 #pragma unroll 1
                 for (int r = 0; r < RS; ++r)
@@ -1293,6 +1319,7 @@ struct FastRoute
 {
     bool     generic = false; // the launch goes to the generic LDS kernel instead (small launch, or a non-dense dof layout)
     bool     split = false, affine = false, energy = false, multi = false, dynamic = false;
+    bool     strided = false; // the kernel's unknowns are a subset of the node's dofs: 8-byte gather / scatter variant
     int      waves_cu = 0, xcd_chunk = 0, n_cus = 0;
     unsigned grid = 0;
     int64_t  n_batches = 0;
@@ -1308,17 +1335,20 @@ int planSumfactFast(const ElemArgs& a, FastRoute& r)
     // workgroup of the generic kernel; below ~3 elements per CU the generic kernel wins (profiles/r01_kbench_small_meshes.log:
     // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements): l3k_tuning::generic_below
     constexpr bool generic_fits = applyLdsBytes< K, P, NQ, 1 >() <= lds_limit_bytes;
-    if (!a.dense || (generic_fits && a.elem_count < tune.generic_below)) // (non-dense dof layouts: generic kernel only)
+    // (non-dense dof layouts: the strided variant -- plain single-column applies; with the fused energy or several columns the
+    // generic kernel)
+    if ((!a.dense && (MULTI || a.energy != nullptr || a.fuse_beta)) || (generic_fits && a.elem_count < tune.generic_below))
     {
         r.generic = true;
         return 0;
     }
+    r.strided = !a.dense;
     // (ghost rows directly behind the owned rows of every column: one base pointer per column serves both)
     const bool contiguous = (a.xg == nullptr || (a.xg == a.x + a.n_owned_dofs && (!MULTI || a.ldxg == a.ldx))) &&
                             (a.yg == nullptr || (a.yg == a.y + a.n_owned_dofs && (!MULTI || a.ldyg == a.ldy)));
     r.split  = !contiguous;
     // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
-    r.affine = !MULTI && a.all_affine && !r.split && !a.energy && !tune.no_affine;
+    r.affine = !MULTI && a.all_affine && !r.split && !a.energy && !tune.no_affine && !r.strided;
     r.energy = !MULTI && a.energy != nullptr;
     // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
     // attribute of the variants is set once on each device, under a lock
@@ -1350,7 +1380,9 @@ int planSumfactFast(const ElemArgs& a, FastRoute& r)
                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, true >),
                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false >),
                             reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false >),
-                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, true >)};
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, true >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false, false, false, true >),
+                            reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, false, false, true >)};
             bool ok = true;
             for (const void* f : variants)
                 ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) == hipSuccess;
@@ -1426,6 +1458,8 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
     decltype(&sumfactFastKernel< K, P, NQ, false, false >) kernel;
     if constexpr (MULTI) // (no fused energy, no affine variant: plain applies of several columns)
         kernel = r.split ? sumfactFastKernel< K, P, NQ, true, false, false, true > : sumfactFastKernel< K, P, NQ, false, false, false, true >;
+    else if (r.strided)
+        kernel = r.split ? sumfactFastKernel< K, P, NQ, true, false, false, false, true > : sumfactFastKernel< K, P, NQ, false, false, false, false, true >;
     else
         kernel = r.affine ? sumfactFastKernel< K, P, NQ, false, false, true >
                  : r.energy ? (r.split ? sumfactFastKernel< K, P, NQ, true, true > : sumfactFastKernel< K, P, NQ, false, true >)
@@ -1467,10 +1501,10 @@ int describeSumfactFast(const ElemArgs& a, char* buf, size_t n)
     if (r.generic)
         return describeSumfactApply< K, P, NQ, 1 >(a, buf, n);
     std::snprintf(buf, n,
-                  "sumfactFastKernel<p=%d,nq=%d,U=%d,F=%d>%s%s%s%s: one wave per %d element(s), %d of 64 lanes, %zu B LDS/wave, "
+                  "sumfactFastKernel<p=%d,nq=%d,U=%d,F=%d>%s%s%s%s%s: one wave per %d element(s), %d of 64 lanes, %zu B LDS/wave, "
                   "%d waves/CU x %d CUs = grid %u, %s batches%s",
                   P, NQ, Cfg::U, Cfg::F, r.affine ? " affine" : "", r.energy ? " energy" : "", r.split ? " split-ghost" : "",
-                  r.multi ? " multi-column" : "", Cfg::EW, Cfg::EW * Cfg::TEAM, size_t(Cfg::lds), r.waves_cu, r.n_cus, r.grid,
+                  r.multi ? " multi-column" : "", r.strided ? " strided-dofs" : "", Cfg::EW, Cfg::EW * Cfg::TEAM, size_t(Cfg::lds), r.waves_cu, r.n_cus, r.grid,
                   r.dynamic ? "dynamic" : "static", r.xcd_chunk ? ", XCD-chunked" : "");
     return 0;
 }

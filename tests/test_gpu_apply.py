@@ -143,6 +143,65 @@ def test_subset_of_node_dofs_and_leading_dimension(ctx):
         np.testing.assert_array_equal(out[:, k:n:dpn], yb[:, k:n:dpn])
 
 
+@pytest.mark.parametrize("kid,p,dpn,fi,kpar", [(system.KERNEL_DIFFUSION3D, 2, 6, [4, 0, 5, 2], [0.7, 1.3]), (system.KERNEL_DIFFUSION3D, 4, 5, [1, 2, 3, 4], [1.0, 1.0]),
+                                               (system.KERNEL_DIFFUSION3D, 6, 6, [5, 3, 1, 0], [0.7, 1.3]), (system.KERNEL_DIVCURL3D, 4, 5, [3, 1, 4], [0.6]),
+                                               (system.KERNEL_ADVECTION3D, 6, 3, [2], [0.05]), (system.KERNEL_ADVDIFF3D, 4, 7, [6, 0, 2, 3], None)])
+def test_subset_of_node_dofs_on_the_single_wave_kernel(ctx, kid, p, dpn, fi, kpar):
+    """Kernels whose unknowns are a SUBSET of the node's dofs (field_inds: detail::getDofs, MatrixFreeSystem.hpp:298-311 -- several
+    kernels sharing one dof map) take the one-wave-per-element kernel too, in its strided-dof variant (8-byte gather / scatter, every
+    node through the atomic path): route asserted; y <- alpha A x + beta y against the oracle incl. Dirichlet dofs, dofs outside
+    field_inds only scaled by beta; then a rank with ghosts, ghost rows in buffers of their own (the owned-or-ghost select)."""
+    info = system.kernel_info(kid)
+    U, F = info["n_unknowns"], info["n_fields"]
+    part = system.CubePartition(3, p, perturb=0.1)
+    mask = np.zeros((part.n_local_nodes, dpn), np.uint8)
+    mask[part.node_boundary != 0, fi[0]] = 1
+    mask[::7, fi[-1]] = 1
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, dpn, mask.reshape(-1)), kid, kpar, field_inds=fi)
+    fields = np.random.default_rng(2).uniform(-1, 1, (F, part.n_local_nodes)) if F else None
+    if F:
+        mf.set_fields(dev(fields))
+    assert mf.route().startswith(f"sumfactFastKernel<p={p},") and "strided-dofs" in mf.route(), mf.route()
+    n = part.n_local_nodes * dpn
+    rng = np.random.default_rng(4)
+    xb, yb = rng.uniform(-1, 1, (1, n)), rng.uniform(-1, 1, (1, n))
+    X, Y = dev(xb), dev(yb)
+    mf.apply(X, Y, 2.0, 0.5)
+    om = oracle_mesh(part, p + 1, dpn, fi, mask.reshape(-1), fields=fields)
+    y_ref = O.mf_apply(om, kid, xb.T, np.asfortranarray(yb.T.copy()), alpha=2.0, beta=0.5, kparams=kpar)
+    out = Y.cpu().numpy()
+    assert rel_err(out.T, y_ref) < 1e-11
+    for k in np.setdiff1d(np.arange(dpn), fi):
+        np.testing.assert_array_equal(out[:, k:n:dpn], 0.5 * yb[:, k:n:dpn])
+    # the same kernel on the generic route agrees to rounding
+    with ctx.tuning(generic_below=10 ** 9):
+        assert mf.route().startswith("sumfactApplyKernel")
+        Yg = dev(yb)
+        mf.apply(X, Yg, 2.0, 0.5)
+    assert rel_err(Yg.cpu().numpy().T, out.T) < 1e-12
+    # a rank with ghosts: separate ghost buffers against ghost rows behind the owned rows
+    part2 = system.CubePartition((4, 4, 2), p, parts=(2, 2, 1), rank=3, perturb=0.1)
+    mask2 = np.zeros((part2.n_local_nodes, dpn), np.uint8)
+    mask2[part2.node_boundary != 0, fi[0]] = 1
+    mf2 = system.MatrixFreeSystem(system.DeviceMesh(ctx, part2, dpn, mask2.reshape(-1)), kid, kpar, field_inds=fi)
+    if F:
+        mf2.set_fields(dev(np.random.default_rng(3).uniform(-1, 1, (F, part2.n_local_nodes))))
+    n_owned, n_ghost = part2.n_owned_nodes * dpn, part2.n_ghost_nodes * dpn
+    x2 = dev(np.random.default_rng(5).uniform(-1, 1, (1, n_owned + n_ghost)))
+    Y2 = torch.zeros((1, n_owned), dtype=torch.float64, device="cuda")
+    YG = torch.zeros((1, n_ghost), dtype=torch.float64, device="cuda")
+    mf2.apply_elems(2, x2[:, :n_owned].clone(), x2[:, n_owned:].clone(), Y2, YG, 1.5, 0.0)
+    yc = torch.zeros_like(x2)
+    mf2.apply_elems(2, x2[:, :n_owned], x2[:, n_owned:], yc[:, :n_owned], yc[:, n_owned:], 1.5, 0.0)
+    with ctx.tuning(generic_below=10 ** 9):
+        yg = torch.zeros_like(x2)
+        mf2.apply_elems(2, x2[:, :n_owned], x2[:, n_owned:], yg[:, :n_owned], yg[:, n_owned:], 1.5, 0.0)
+    torch.cuda.synchronize()
+    scale = float(yg.abs().max())
+    assert float((yc[:, :n_owned] - Y2).abs().max()) < 1e-12 * scale and float((yc[:, n_owned:] - YG).abs().max()) < 1e-12 * scale
+    assert float((yc - yg).abs().max()) < 1e-12 * scale and float(YG.abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("ne,p", [(16, 4), (12, 6)])
 def test_operator_properties_at_scale(ctx, ne, p):
     """Size-independent properties on a mesh too large for the oracle to be the first resort: symmetry
