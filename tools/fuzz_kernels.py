@@ -2,7 +2,9 @@
 the point and the time), Advection3D (U = 1, F = 3), DivCurl3D (U = 3), AdvDiff3D (F = 3) at every instantiated (order, nq); random
 mesh extents, geometry perturbation, Dirichlet sides / unknowns, alpha / beta, time, fields; the one-wave-per-element and the generic
 route (l3k_tuning::generic_below drawn per case), the reference's z = 0 mode on a fraction of the cases (oracle with the same switch),
-deterministic mode on a fraction; diag + lifted rhs on a third, K_e / F_e of a random element entry by entry on a tenth (orders <= 4).
+deterministic mode on a fraction; diag + lifted rhs on a third, K_e / F_e of a random element entry by entry on a tenth (orders <= 4);
+on a third of the cases the kernel's unknowns are a random SUBSET of a wider dof map (dofs_per_node up to U + 3, random field_inds:
+the strided-dof variant of the one-wave kernel or the generic kernel).
 Prints the worst relative error; exits non-zero on a case above 1e-11.
     python tools/fuzz_kernels.py [--seconds 300] [--seed 0]"""
 import argparse, os, sys, time
@@ -41,19 +43,28 @@ while time.time() < t_end:
     det, z0, t = rng.random() < 0.2, rng.random() < 0.25, float(rng.choice([0.0, rng.uniform(-1, 1)]))
     below = int(rng.choice([0, 1500, 10 ** 9]))
     part = system.CubePartition(ne, p, perturb=perturb)
-    mask = part.dirichlet_mask(U, unknowns=unknowns, sides=sides)
+    subset = rng.random() < 0.33
+    dpn = U + int(rng.integers(1, 4)) if subset else U
+    fi = [int(v) for v in rng.permutation(dpn)[:U]] if subset else list(range(U))
+    mask_u = part.dirichlet_mask(U, unknowns=unknowns, sides=sides).reshape(-1, U)
+    mask = np.zeros((part.n_local_nodes, dpn), np.uint8)
+    mask[:, fi] = mask_u
+    if subset:  # (Dirichlet flags on dofs of other kernels must not matter)
+        others = np.setdiff1d(np.arange(dpn), fi)
+        mask[:, others] = rng.random((part.n_local_nodes, len(others))) < 0.2
+    mask = mask.reshape(-1)
     ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
     ctx.set_tuning(generic_below=below)
     if det:
         ctx.set_deterministic(True)
     ctx.set_reference_z0(z0)
-    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, U, mask), kid, KPAR[kid], asm_opts=(vo, 0, 0))
+    mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, dpn, mask), kid, KPAR[kid], asm_opts=(vo, 0, 0), field_inds=fi if subset else None)
     fields = rng.uniform(-1, 1, (F, part.n_local_nodes)) if F else None
     if F:
         mf.set_fields(dev(fields))
     mf.set_time(t)
-    om = oracle_mesh(part, nq, U, np.arange(U), mask, fields)
-    x = part.synthetic_vector(U, seed=int(rng.integers(1 << 30)))
+    om = oracle_mesh(part, nq, dpn, np.asarray(fi), mask, fields)
+    x = part.synthetic_vector(dpn, seed=int(rng.integers(1 << 30)))
     y0 = rng.uniform(-1, 1, x.shape)
     O.set_reference_z0(z0)
     try:
@@ -65,9 +76,9 @@ while time.time() < t_end:
     torch.cuda.synchronize()
     err = rel_err(Y.cpu().numpy().T, y_ref)
     case = dict(kernel=info["name"], p=p, nq=nq, ne=ne, perturb=perturb, alpha=alpha, beta=beta, sides=sides, unknowns=unknowns, det=det,
-                z0=z0, time=t, generic_below=below, route=mf.route().split(":")[0])
+                z0=z0, time=t, generic_below=below, route=mf.route().split(":")[0], dpn=dpn, field_inds=fi)
     if rng.random() < 0.33:  # diag + lifted rhs (the reference's local-element path: true point in both modes)
-        g = rng.uniform(-1, 1, (1, part.n_local_nodes * U)) * mask[None, :]
+        g = rng.uniform(-1, 1, (1, part.n_local_nodes * dpn)) * mask[None, :]
         diag, rhs = mf.diag_rhs(dev(g))
         torch.cuda.synchronize()
         d_ref, r_ref = O.mf_diag_rhs(om, kid, 1, np.asfortranarray(g.T), kparams=KPAR[kid], time=t)
