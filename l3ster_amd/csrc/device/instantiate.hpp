@@ -39,19 +39,18 @@ namespace l3k::dev
 {
 // R columns through the one-wave-per-element kernel, one column per launch: at order 6 it is ~3x faster per column than
 // the generic LDS kernel, so R launches beat one R-column launch (the apply never reads the kernel's rhs, so the
-// single-column instantiation of the functor gives the same operator); other dof layouts go to the generic kernel
+// single-column instantiation of the functor gives the same operator); unknowns on a subset of the node's dofs: column by
+// column through the strided-dof variant
 template < typename T, int P, int NQ, int R >
 int launchColumnsFast(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
 {
-    if (!a.dense)
-        return launchSumfactApply< T, P, NQ, R, false >(a, kparam_blob, stream);
     if constexpr (FastCfg< T, P, NQ >::multi_column)
-    {
-        ElemArgs ac = a; // all R columns in one pass over the elements (the multi-column variant of the single-wave kernel)
-        ac.n_cols   = R;
-        return launchSumfactFastCols< T, P, NQ >(ac, kparam_blob, stream);
-    }
-    else
+        if (a.dense)
+        {
+            ElemArgs ac = a; // all R columns in one pass over the elements (the multi-column variant of the single-wave kernel)
+            ac.n_cols   = R;
+            return launchSumfactFastCols< T, P, NQ >(ac, kparam_blob, stream);
+        }
     {
         for (int c = 0; c < R; ++c)
         {
@@ -92,12 +91,10 @@ constexpr RouteFn selectRoute()
         return &describeSumfactFast< T, P, NQ >;
     else if constexpr (FastCfg< T, P, NQ >::feasible)
         return +[](const ElemArgs& a, char* buf, size_t n) {
-            if (!a.dense)
-                return describeSumfactApply< T, P, NQ, R >(a, buf, n);
             ElemArgs ac = a; // launchColumnsFast: one multi-column pass, or R launches of the single-column kernel
-            ac.n_cols   = R;
+            ac.n_cols   = a.dense ? R : 1;
             const int rc = describeSumfactFast< T, P, NQ >(ac, buf, n);
-            if (rc == 0 && !FastCfg< T, P, NQ >::multi_column)
+            if (rc == 0 && (!FastCfg< T, P, NQ >::multi_column || !a.dense))
                 std::snprintf(buf + std::strlen(buf), n - std::strlen(buf), "; %d launches, one per column", R);
             return rc;
         };

@@ -127,6 +127,7 @@ def test_subset_of_node_dofs_and_leading_dimension(ctx):
     mask[part.node_boundary != 0, 4] = 1
     mesh = system.DeviceMesh(ctx, part, dpn, mask.reshape(-1))
     mf = system.MatrixFreeSystem(mesh, system.KERNEL_DIFFUSION3D, field_inds=fi, n_rhs=2)
+    assert "strided-dofs" in mf.route(2, 2) and "one per column" in mf.route(2, 2), mf.route(2, 2)  # (the test suite sets generic_below = 0)
     n = part.n_local_nodes * dpn
     pad = 37
     rng = np.random.default_rng(4)
