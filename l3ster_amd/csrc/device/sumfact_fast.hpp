@@ -1335,9 +1335,9 @@ int planSumfactFast(const ElemArgs& a, FastRoute& r)
     // workgroup of the generic kernel; below ~3 elements per CU the generic kernel wins (profiles/r01_kbench_small_meshes.log:
     // order 6, 216 elements 16 vs 32 us, 1000 elements 34 vs 44 us, crossover at ~1700 elements): l3k_tuning::generic_below
     constexpr bool generic_fits = applyLdsBytes< K, P, NQ, 1 >() <= lds_limit_bytes;
-    // (non-dense dof layouts: the strided variant -- plain single-column applies; with the fused energy or several columns the
-    // generic kernel)
-    if ((!a.dense && (MULTI || a.energy != nullptr || a.fuse_beta)) || (generic_fits && a.elem_count < tune.generic_below))
+    // (non-dense dof layouts: the strided variant -- single-column applies; it does not accumulate x^T A x: the caller's
+    // l3k_mf_energy_end then reports "not fused" and the dot product runs as a pass of its own)
+    if ((!a.dense && (MULTI || a.fuse_beta)) || (generic_fits && a.elem_count < tune.generic_below))
     {
         r.generic = true;
         return 0;
@@ -1349,7 +1349,7 @@ int planSumfactFast(const ElemArgs& a, FastRoute& r)
     r.split  = !contiguous;
     // (the affine variant exists for the plain apply: no ghost buffers, no fused energy)
     r.affine = !MULTI && a.all_affine && !r.split && !a.energy && !tune.no_affine && !r.strided;
-    r.energy = !MULTI && a.energy != nullptr;
+    r.energy = !MULTI && a.energy != nullptr && !r.strided;
     // launch configuration per device (several contexts of one process may sit on different GPUs): the dynamic-LDS
     // attribute of the variants is set once on each device, under a lock
     struct PerDevice
@@ -1479,7 +1479,7 @@ int launchSumfactFastImpl(const ElemArgs& a, const void* kparam_blob, hipStream_
         return -3;
     }
     hipLaunchKernelGGL(kernel, dim3(r.grid), dim3(64), Cfg::lds, stream, a, kern, r.n_batches, r.xcd_chunk, tab);
-    if (a.energy && a.energy_done)
+    if (r.energy && a.energy_done)
         ++*a.energy_done;
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)

@@ -161,6 +161,47 @@ def test_k1_three_right_hand_sides_through_the_device_solver():
 
 
 @pytest.mark.gpu
+def test_pcg_on_a_subset_of_the_node_dofs():
+    """A system whose kernel acts on 4 of 6 dofs per node (field_inds): the device PCG runs its applies on the strided-dof variant of
+    the one-wave kernel (which does not fuse <p, A p>: the dot product runs as a pass of its own), the dofs of other kernels are
+    frozen rows (zero preconditioner entries) -- and the solution on the kernel's dofs is the one of the same problem on a dense
+    dof map."""
+    import numpy as np
+    import torch
+    from l3ster_amd import solve, system
+    torch.cuda.set_device(0)
+    ctx = system.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_tuning(generic_below=0)
+    p, U, dpn, fi = 4, 4, 6, [4, 0, 5, 2]
+    part = system.CubePartition(4, p, perturb=0.1)
+    mask_u = part.dirichlet_mask(U, unknowns=[0]).reshape(-1, U)
+    g_u = np.zeros((part.n_local_nodes, U))
+    g_u[:, 0] = part.node_coords()[:, 0] * mask_u[:, 0]  # T = x on the boundary
+    sols = {}
+    for name in ("dense", "subset"):
+        d, f = (U, list(range(U))) if name == "dense" else (dpn, fi)
+        mask = np.zeros((part.n_local_nodes, d), np.uint8)
+        mask[:, f] = mask_u
+        g = np.zeros((part.n_local_nodes, d))
+        g[:, f] = g_u
+        mf = system.MatrixFreeSystem(system.DeviceMesh(ctx, part, d, mask.reshape(-1)), system.KERNEL_DIFFUSION3D, [1.0, 0.0],
+                                     field_inds=None if name == "dense" else f)
+        if name == "subset":
+            assert "strided-dofs" in mf.route(2, 1, True) and " energy" not in mf.route(2, 1, True), mf.route(2, 1, True)
+        diag, rhs = mf.diag_rhs(torch.as_tensor(g.reshape(1, -1), device="cuda"))
+        minv = torch.where(diag != 0, 1.0 / diag, torch.zeros_like(diag))
+        x = torch.zeros_like(rhs[0])
+        r = solve.pcg(mf, rhs[0].contiguous(), x, minv, tol=1e-12, residual_scaling="rhs", max_iters=5000)
+        assert r.converged
+        sols[name] = x.cpu().numpy().reshape(-1, d)[:, f]
+        if name == "subset":  # the other kernels' dofs: untouched
+            others = np.setdiff1d(np.arange(d), f)
+            assert np.all(x.cpu().numpy().reshape(-1, d)[:, others] == 0.0)
+    assert np.abs(sols["subset"] - sols["dense"]).max() < 1e-9 * np.abs(sols["dense"]).max()
+    assert np.abs(sols["dense"][:, 0] - part.node_coords()[:, 0]).max() < 1e-8  # (T = x, the reference's K1 / K6 solution)
+
+
+@pytest.mark.gpu
 def test_pcg_with_zero_preconditioner_entries():
     """the iteration keeps z = M^-1 r, and r = z / minv was 0 / 0 = NaN on rows where the caller's preconditioner is
     zero (the common way to freeze constrained dofs; l3k_jacobi_inverse with damping 0).  Such rows are frozen now: x keeps its
