@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__((SfAsmCfg< P, NQ >::threadsFor(TMODE != 0, BLOCKS))
             // W[bz][s'][qz] = sum_s B[s + 2 s'][qz] T_s[bz][qz]: 4 nq n + 2 nq n^2 = 882 FMAs per row instead of 4 nq n^2 = 1 372,
             // and every scalar operand of the second step (the 1-D tables through scalar loads) serves a block of ZB values of bz
             // instead of one entry -- the first form waited for its scalar loads (56 scalar registers per column)
-            constexpr int ZB = TILED && P >= 7 ? 1 : 2; // (the tiled store at order 7: one, 39 -> 46 k stored matrices/s; orders 5, 6: no difference)  values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills;
+            constexpr int ZB = (TILED && P >= 7) || (!TILED && P == 6) ? 1 : 2; // (the tiled store at order 7: one, 39 -> 46 k stored matrices/s; orders 5, 6: no difference; the streaming kernels at order 6: one -- the off-diagonal kernel spills 1 instead of 10 registers, 534 -> 539 k matrices/s)  values of bz per block: W of a block is 2 ZB nq doubles of registers (4: the same rate, more spills;
                                   // with the DPP tables 1 / 2 / 4 at order 6: 458 / 450 / 446 k, but 1 loses 12 % at order 4)
             const __attribute__((address_space(4))) double* const tIz =
                 reinterpret_cast< const __attribute__((address_space(4))) double* >(reinterpret_cast< uintptr_t >(a.tables + TL.offI()));
