@@ -9,6 +9,7 @@
 #define L3K_DEVICE_DIAG_HPP
 
 #include "sumfact_apply.hpp"
+#include "sumfact_fast.hpp"
 
 namespace l3k::dev
 {
@@ -156,8 +157,16 @@ int launchDiagRhs(const ElemArgs& a, const void* kparam_blob, hipStream_t stream
 {
     if (a.elem_count <= 0)
         return 0;
-    if (int rc = launchSumfactApply< K, P, NQ, R, true >(a, kparam_blob, stream))
-        return rc;
+    // the right-hand side: the single-wave kernel's RHS variant where it applies (one column, dense dof layout, not a small
+    // launch), else the generic kernel in RHS mode
+    int rhs_rc = 1;
+    if constexpr (R == 1 && FastCfg< K, P, NQ >::feasible)
+        rhs_rc = launchSumfactFastRhs< K, P, NQ >(a, kparam_blob, stream);
+    if (rhs_rc < 0)
+        return rhs_rc;
+    if (rhs_rc == 1)
+        if (int rc = launchSumfactApply< K, P, NQ, R, true >(a, kparam_blob, stream))
+            return rc;
     if (!a.diag)
         return 0;
     K kern{};

@@ -314,7 +314,11 @@ struct FastCfg
 // STRIDED: the kernel's unknowns are a subset of the node's dofs (dof = node * dofs_per_node + field_inds[u]: detail::getDofs,
 // algsys/MatrixFreeSystem.hpp:298-311): 8-byte gather and scatter accesses, every node through the atomic path (the rows of such
 // a vector hold other kernels' dofs, which the pre-scaling pass must not skip).  Plain applies only (no fused energy, one column).
-template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false, bool STRIDED = false >
+// RHS: the right-hand side with Dirichlet lifting instead of the apply (precomputeOperatorDiagonalAndRhs' rhs term,
+// algsys/EvaluateLocalOperator.hpp:172-208: rhs += B^T W (f - B g) with g = the Dirichlet values on the Dirichlet dofs and 0
+// elsewhere): the gather reads a.dirichlet_vals where the mask is set, the quadrature stage runs in its RHS form, the scatter adds
+// into every row (Dirichlet rows are overwritten by the finalize pass) through the atomic path, alpha = 1.  One rhs column.
+template < typename K, int P, int NQ, bool SPLIT, bool ENERGY, bool AFFINE = false, bool MULTI = false, bool STRIDED = false, bool RHS = false >
 __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) void sumfactFastKernel(const ElemArgs a, const K kern, int64_t n_batches,
                                                         int xcd_chunk, const FastTables< P + 1, NQ > tab)
 {
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
     constexpr int U = Cfg::U, F = Cfg::F, NF = Cfg::NF, NG = Cfg::NG, UG = Cfg::UG, NN = N1 * N1 * N1;
     constexpr int DG = Cfg::DG, DF = Cfg::DF; // groups / fields whose derivatives are formed
     static_assert(!STRIDED || (!ENERGY && !AFFINE && !MULTI));
+    static_assert(!RHS || (!ENERGY && !AFFINE && !MULTI && !STRIDED));
     [[maybe_unused]] const int dpn = a.dofs_per_node; // (STRIDED)
     // bit u: dof u of the kernel at `node` is a Dirichlet dof
     auto dirBits = [&](int64_t node) -> uint32_t {
@@ -479,7 +484,14 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
             const int64_t node = ids[k];
             const double* p    = STRIDED ? (!SPLIT || node < n_owned_nodes ? ax + node * dpn : axg + (node - n_owned_nodes) * dpn)
                                          : (!SPLIT || node < n_owned_nodes ? ax + node * U : axg + (node - n_owned_nodes) * U);
-            if constexpr (STRIDED) // a subset of the node's dofs: one 8-byte load per unknown
+            if constexpr (RHS) // g: the Dirichlet values on the Dirichlet dofs (one array over all local dofs), 0 elsewhere
+            {
+                const uint32_t dm = flagged ? dirBits(node) : 0u;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xn[k][u] = (dm >> u) & 1u ? a.dirichlet_vals[node * U + u] : 0.;
+            }
+            else if constexpr (STRIDED) // a subset of the node's dofs: one 8-byte load per unknown
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 for (int u = 0; u < U; ++u)
                     xn[k][u] = (L3K_DBG(a) & 2) ? 1e-9 * double(node) : p[u];
             }
-            dm_nxt[k] = flagged ? dirBits(node) : 0u;
+            dm_nxt[k] = !RHS && flagged ? dirBits(node) : 0u;
 #pragma unroll
             for (int f = 0; f < F; ++f)
                 fn[k][f] = a.fields[node + f * a.ldf];
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
         // one masked region for everything up to the scatter: the lanes without a pencil (helpers of the scatter) skip it
         if (w_all)
         {
-        loadX(w_nn, ids_cur, (flag_cur & 1u) != 0);
+        loadX(w_nn, ids_cur, RHS ? (a.dirichlet_vals != nullptr && ((flag_cur & 1u) != 0 || !have_flags)) : (flag_cur & 1u) != 0);
         // ---- take over the prefetched data (gatherSumFact: Dirichlet dofs read as 0, MatrixFreeSystem.hpp:441-466)
         double u0[N1][2 * NG];
         if (w_nn)
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     u0[k][u] = xn[k][u];
-                if ((flag_cur & 1u) != 0) // only elements touching a Dirichlet dof pay for the masking
+                if (!RHS && (flag_cur & 1u) != 0) // only elements touching a Dirichlet dof pay for the masking
                 {
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -772,7 +784,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
             [[maybe_unused]] double en = 0.; // ENERGY (in-stage form): this pencil's share of x^T A x
             // (qw[q] * wyz is formed per point: hoisted, the 7 products cost 14 registers.)  alpha rides on the weight, so the
             // staged result needs no scaling pass; the ENERGY variant accumulates the unscaled x^T A x and scales at the end
-            const double wyz = opaqueCopy(wyz_l) * (ENERGY ? 1. : a.alpha);
+            const double wyz = opaqueCopy(wyz_l) * (ENERGY || RHS ? 1. : a.alpha);
             double       G[6][3];
             if constexpr (VREG && EW == 1)
             {
@@ -834,10 +846,10 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 if constexpr (AFFINE)
                 {
                     const double xyz[3] = {G[0][0] + qp[q] * G[1][0], G[0][1] + qp[q] * G[1][1], G[0][2] + qp[q] * G[1][2]};
-                    qpStageAt< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
+                    qpStageAt< K, 1, RHS, 1, 0, ENERGY && !ENERGY_AT_END >(kern, Ji0, det0, xyz, qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
                 }
                 else
-                    qpStage< K, 1, false, 1, 0, ENERGY && !ENERGY_AT_END >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
+                    qpStage< K, 1, RHS, 1, 0, ENERGY && !ENERGY_AT_END >(kern, G, qp[q], qw[q] * wyz, a.time, vv, dv, r0, rd, &en, a.ref_z0 != 0);
 #pragma unroll
                 for (int o = 0; o < U; ++o)
                 {
@@ -1030,7 +1042,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 // with a mask byte load per dof and round: the chunks holding Dirichlet faces ran 7 % longer).  The mask bytes
                 // are fetched again here instead of kept from the gather (registers)
 #ifndef L3K_FLAGGED_SCATTER // (A/B switch: the round-2 form with a scatter path of its own for flagged elements)
-                if ((flag_cur & 1u) != 0)
+                if (!RHS && (flag_cur & 1u) != 0) // (RHS: every row receives its share; the finalize pass overwrites the Dirichlet rows)
 #else
                 if (false)
 #endif
@@ -1219,7 +1231,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                 exclStore(dst, out);
             };
             constexpr int RS = (Cfg::NSH * U + SG - 1) / SG, RX = ((NN - Cfg::NSH) * UX + SG - 1) / SG;
-            if (!STRIDED && a.fuse_beta && !flagged)
+            if (!STRIDED && !RHS && a.fuse_beta && !flagged)
             {
 #ifdef L3K_ABLATION
 #pragma unroll
@@ -1269,7 +1281,7 @@ __global__ __launch_bounds__(64, (FastCfg< K, P, NQ >::wavesPerSimd(MULTI))) voi
                     }
 #endif
             }
-            else if (!STRIDED && a.fuse_beta)
+            else if (!STRIDED && !RHS && a.fuse_beta)
             {
 #pragma unroll 1
                 for (int r = 0; r < RS; ++r)
@@ -1506,6 +1518,75 @@ int describeSumfactFast(const ElemArgs& a, char* buf, size_t n)
                   P, NQ, Cfg::U, Cfg::F, r.affine ? " affine" : "", r.energy ? " energy" : "", r.split ? " split-ghost" : "",
                   r.multi ? " multi-column" : "", r.strided ? " strided-dofs" : "", Cfg::EW, Cfg::EW * Cfg::TEAM, size_t(Cfg::lds), r.waves_cu, r.n_cus, r.grid,
                   r.dynamic ? "dynamic" : "static", r.xcd_chunk ? ", XCD-chunked" : "");
+    return 0;
+}
+// the right-hand side of one column with Dirichlet lifting on the single-wave kernel (RHS variant); returns 1 where the launch
+// belongs to the generic kernel in RHS mode (small launches, other dof layouts, element-local output, several columns)
+template < typename K, int P, int NQ >
+int launchSumfactFastRhs(const ElemArgs& a, const void* kparam_blob, hipStream_t stream)
+{
+    using Cfg = FastCfg< K, P, NQ >;
+    if (a.elem_count <= 0)
+        return 0;
+    if (!a.dense || a.local_out || a.n_cols > 1)
+        return 1;
+    ElemArgs ar  = a;
+    ar.energy    = nullptr;
+    ar.fuse_beta = 0;
+    ar.alpha     = 1.;
+    ar.beta      = 1.;
+    ar.x         = a.y; // (unused by the gather; the pointer relations below decide the ghost-buffer variant)
+    ar.xg        = a.yg;
+    FastRoute r;
+    if (int rc = planSumfactFast< K, P, NQ, false >(ar, r))
+        return rc;
+    if (r.generic)
+        return 1;
+    {
+        static std::mutex attr_mutex;
+        static bool       attr_set[64] = {};
+        int               dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard< std::mutex > lock{attr_mutex};
+        if (dev >= 0 && dev < 64 && !attr_set[dev])
+        {
+            if (hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, true, false, false, false, false, true >),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast< const void* >(sumfactFastKernel< K, P, NQ, false, false, false, false, false, true >),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(Cfg::lds)) != hipSuccess)
+            {
+                setError("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", Cfg::lds);
+                return -3;
+            }
+            attr_set[dev] = true;
+        }
+    }
+    K kern{};
+    if (kparam_blob)
+        __builtin_memcpy(&kern, kparam_blob, sizeof(K));
+    auto kernel = r.split ? sumfactFastKernel< K, P, NQ, true, false, false, false, false, true >
+                          : sumfactFastKernel< K, P, NQ, false, false, false, false, false, true >;
+    constexpr TableLayout   TL{P + 1, NQ};
+    FastTables< P + 1, NQ > tab;
+    const double*           th = a.tables_host;
+    __builtin_memcpy(tab.eoI, th + TL.offEoI(), sizeof tab.eoI);
+    __builtin_memcpy(tab.eoC, th + TL.offEoC(), sizeof tab.eoC);
+    __builtin_memcpy(tab.eoIt, th + TL.offEoIt(), sizeof tab.eoIt);
+    __builtin_memcpy(tab.eoCt, th + TL.offEoCt(), sizeof tab.eoCt);
+    __builtin_memcpy(tab.qw, th + TL.offW(), sizeof tab.qw);
+    __builtin_memcpy(tab.qx, th + TL.offX(), sizeof tab.qx);
+    if (ar.work_counters && hipMemsetAsync(ar.work_counters, 0, 8 * 128, stream) != hipSuccess)
+    {
+        setError("hipMemsetAsync(work counters) failed");
+        return -3;
+    }
+    hipLaunchKernelGGL(kernel, dim3(r.grid), dim3(64), Cfg::lds, stream, ar, kern, r.n_batches, r.xcd_chunk, tab);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+    {
+        setError("sumfactFastKernel (rhs) launch failed: %s", hipGetErrorString(err));
+        return -3;
+    }
     return 0;
 }
 template < typename K, int P, int NQ >
