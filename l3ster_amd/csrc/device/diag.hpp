@@ -17,7 +17,7 @@ template < typename K, int P, int NQ >
 constexpr size_t diagLdsBytes()
 {
     constexpr int M = cmax(P + 1, NQ);
-    return sizeof(double) * (size_t(4 * K::params.n_unknowns + 5 * K::params.n_fields) * M * M * M + 24);
+    return sizeof(double) * (size_t(4 * K::params.n_unknowns + 5 * K::params.n_fields + 13) * M * M * M + 24); // (+ 13: Ji, w detJ, point)
 }
 
 // GS: working set in the workgroup's slice of a.scratch instead of the LDS, persistent workgroups (sumfact_apply.hpp)
@@ -37,7 +37,8 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const El
     double* const            T2  = T1 + U * M3;
     double* const            acc = T2 + U * M3;      // [U][M3] element diagonal at the nodes
     double* const            Fv  = acc + U * M3;     // fields at the QPs: values, then 3 reference derivatives, + 1 temp
-    double* const            vs  = Fv + 5 * F * M3;  // [8][3]
+    double* const            geo = Fv + 5 * F * M3;  // [13][M3]: J^-1 (9), w detJ, the point (3) at the quadrature points, formed once per element
+    double* const            vs  = geo + 13 * M3;    // [8][3]
 
     const int       tid = threadIdx.x;
     const double*   tab[3] = {a.tables + TL.offII(), a.tables + TL.offID(), a.tables + TL.offDD()};
@@ -76,18 +77,39 @@ __global__ __launch_bounds__((applyThreads< P, NQ >())) void diagKernel(const El
         sweep< 2, NQ, NQ, false, false, NQ, NQ, NQ, F, NT >(Fv, Fv + 3 * F * M3, M3, tabC, tid);
     }
     __syncthreads();
+    // the geometry of the element's quadrature points, once (the ten pair steps below read it back: 13 LDS loads instead of ~150
+    // instructions with a division per pair and point)
+    for (int q = tid; q < NQP; q += NT)
+    {
+        const int     qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double* qw = a.tables + TL.offW();
+        const double* qp = a.tables + TL.offX();
+        double        G[6][3], Jm[3][3], Ji[3][3], xyz[3];
+        hexPencilGeom(vs, qp[qy], qp[qz], G);
+        hexPointOnPencil(G, qp[qx], Jm, xyz);
+        const double wgt = qw[qx] * qw[qy] * qw[qz] * inverse3(Jm, Ji);
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            geo[i * M3 + q] = Ji[i / 3][i % 3];
+        geo[9 * M3 + q] = wgt;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            geo[(10 + i) * M3 + q] = xyz[i];
+    }
+    __syncthreads();
 
     auto pairStep = [&]< int KK, int LL >() {
         // ---- G_kl at the quadrature points
         for (int q = tid; q < NQP; q += NT)
         {
-            const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-            const double* qw = a.tables + TL.offW();
-            const double* qp = a.tables + TL.offX();
-            double        G[6][3], Jm[3][3], Ji[3][3], xyz[3];
-            hexPencilGeom(vs, qp[qy], qp[qz], G);
-            hexPointOnPencil(G, qp[qx], Jm, xyz);
-            const double wgt = qw[qx] * qw[qy] * qw[qz] * inverse3(Jm, Ji);
+            double Ji[3][3], xyz[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i)
+                Ji[i / 3][i % 3] = geo[i * M3 + q];
+            const double wgt = geo[9 * M3 + q];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                xyz[i] = geo[(10 + i) * M3 + q];
             typename Iface::DomainInput in;
 #pragma unroll
             for (int f = 0; f < F; ++f)
